@@ -1,0 +1,91 @@
+"""Seeded synthetic Gaussian scenes.  Shapes and activations follow
+scene/gaussian_model.py:132-157,172-199 of the reference: xyz uniform in the AABB
+(dataset/zjumocap.py:419-427), scale = sqrt(clamp_min(distCUDA2, 1e-7)) (gaussian_model.py:186-187),
+opacity = sigmoid(inverse_sigmoid(0.1) + noise) (:191), SH DC = RGB2SH(colour) (:175-180).
+"""
+import math
+
+import torch
+
+C0 = 0.28209479177387814  # utils/sh_utils.py:27
+
+
+def rgb_to_sh(rgb):
+    return (rgb - 0.5) / C0  # utils/sh_utils.py:163
+
+
+def inverse_sigmoid(x):
+    return math.log(x / (1 - x))
+
+
+class GaussianCloud(object):
+    """Post-activation Gaussian state: the tensors `render()` hands to the rasterizer."""
+
+    FIELDS = ("xyz", "scales", "rotations", "opacity", "shs")
+
+    def __init__(self, xyz, scales, rotations, opacity, shs, sh_degree):
+        self.xyz, self.scales, self.rotations, self.opacity, self.shs = xyz, scales, rotations, opacity, shs
+        self.sh_degree = sh_degree
+
+    @property
+    def num(self):
+        return self.xyz.shape[0]
+
+    def to(self, device):
+        return GaussianCloud(*[getattr(self, f).to(device) for f in self.FIELDS], self.sh_degree)
+
+    def covariance6(self, scale_modifier=1.0):
+        """cov3D_precomp (N,6) = strip_symmetric((R S)(R S)^T): scene/gaussian_model.py:28-32,
+        utils/general_utils.py:73-108,194-207."""
+        q = self.rotations / self.rotations.norm(dim=1, keepdim=True)
+        r, x, y, z = q.unbind(1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+        L = R * (scale_modifier * self.scales).unsqueeze(1)
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).contiguous()
+
+    def pack(self):
+        """One flat fp32 buffer [xyz | scales | rotations | opacity | shs]: the broadcast payload of
+        SURVEY.md 8e (tensors 1-6 of GaussianModel.capture(), scene/gaussian_model.py:98-112)."""
+        return torch.cat([getattr(self, f).reshape(-1) for f in self.FIELDS])
+
+    @staticmethod
+    def packed_numel(n, sh_degree):
+        m = (sh_degree + 1) ** 2
+        return n * (3 + 3 + 4 + 1 + 3 * m)
+
+    @staticmethod
+    def unpack(flat, n, sh_degree):
+        m = (sh_degree + 1) ** 2
+        sizes = [3 * n, 3 * n, 4 * n, n, 3 * m * n]
+        parts = torch.split(flat, sizes)
+        return GaussianCloud(parts[0].view(n, 3), parts[1].view(n, 3), parts[2].view(n, 4), parts[3].view(n, 1),
+                             parts[4].view(n, m, 3), sh_degree)
+
+
+def synthetic_cloud(n, sh_degree=3, seed=0, dist2_fn=None, heavy_tail=0.0, device="cpu"):
+    """SURVEY.md 8d scene.  `dist2_fn(points[N,3]) -> [N]` is the distCUDA2 implementation to use
+    (the HIP one on a GPU; tests on CPU pass the oracle's).  `heavy_tail` > 0 multiplies the scales
+    of that fraction of the Gaussians by 4 (BASELINE config 5: tile-overflow / sort stress)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz = torch.rand(n, 3, generator=g) * 2 - 1
+    aniso = torch.exp(torch.randn(n, 3, generator=g) * 0.3)
+    rot = torch.randn(n, 4, generator=g)
+    rot = rot / rot.norm(dim=1, keepdim=True)
+    opacity = torch.sigmoid(inverse_sigmoid(0.1) + torch.randn(n, 1, generator=g))
+    m = (sh_degree + 1) ** 2
+    shs = torch.randn(n, m, 3, generator=g) * 0.05
+    shs[:, 0, :] = rgb_to_sh(torch.rand(n, 3, generator=g))
+    tail = torch.rand(n, generator=g)
+    xyz = xyz.to(device)
+    if dist2_fn is None:
+        from simple_knn._C import distCUDA2 as dist2_fn
+    d2 = torch.as_tensor(dist2_fn(xyz)).to(device=device, dtype=torch.float32)
+    base = torch.sqrt(torch.clamp_min(d2, 1e-7))[:, None]
+    scales = base * aniso.to(device)
+    if heavy_tail > 0:
+        scales = torch.where((tail < heavy_tail).to(device)[:, None], scales * 4.0, scales)
+    return GaussianCloud(xyz.contiguous(), scales.contiguous(), rot.to(device).contiguous(),
+                         opacity.to(device).contiguous(), shs.to(device).contiguous(), sh_degree)

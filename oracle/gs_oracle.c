@@ -1,0 +1,626 @@
+/*
+ * gs_oracle.c -- CPU restatement of the differentiable Gaussian-splat rasterizer
+ * (diff_gaussian_rasterization) and of simple_knn.distCUDA2.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  It is the parity checker for the HIP path and the
+ * "cpu_baseline" leg of bench.py.  Nothing in the shipped package imports, links or calls it.
+ *
+ * PARITY UNPINNED: the reference tree (/root/reference) holds no source for this path
+ * (submodules/diff-gaussian-rasterization and submodules/simple-knn are empty, un-vendored git
+ * submodules without a commit pin -- .gitmodules:1-6, environment.yml:25-26) and no tests or
+ * golden vectors for it.  What the reference DOES pin, and what this file follows:
+ *   - the API generation and argument meaning: gaussian_renderer/__init__.py:85-98,121-141
+ *   - matrix conventions (row-vector, transposed W2C, full_proj = view @ proj^T):
+ *     scene/cameras.py:35-40, utils/graphics_utils.py:38-71
+ *   - quaternion order (w,x,y,z) and rotation matrix: utils/general_utils.py:87-108
+ *   - cov3D six-vector layout [xx,xy,xz,yy,yz,zz]: utils/general_utils.py:73-85
+ *   - covariance = (R S)(R S)^T with S = diag(mod*scale): scene/gaussian_model.py:28-32,
+ *     utils/general_utils.py:194-207
+ *   - the SH polynomial and constants: utils/sh_utils.py:27-44,58-101, "+0.5, clamp_min 0":
+ *     models/texture/texture.py:35-37
+ *   - distCUDA2 call site and its clamp: scene/gaussian_model.py:186
+ * The kernel arithmetic itself is the published algorithm of the third-party dependency
+ * graphdeco-inria/diff-gaussian-rasterization (2023 API generation: 12-field settings tuple,
+ * (color, radii) return) as restated in SURVEY.md section 8a rows A4-A10.
+ *
+ * Arithmetic: fp32, one rounding per operation, in the order written (build with
+ * -ffp-contract=off, no fast-math).  Gradient accumulators over (pixel, Gaussian) pairs are kept
+ * in double: the reference sums float atomics in arbitrary order, so the order-free sum is the
+ * thing to check against.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+typedef struct {
+    int P, deg, M, W, H;
+    const float *bg, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations,
+        *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, tanfovx, tanfovy;
+    int prefiltered;
+} OrArgs;
+
+/* p_view = [p,1] @ viewmatrix (row-vector convention, flat index = row*4 + col):
+ * scene/cameras.py:35 stores W2C transposed, so translation sits at 12..14. */
+static void xform4x3(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+static void xform4x4(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+/* Rotation of a (w,x,y,z) quaternion, NOT renormalised by the kernel (the caller's activation
+ * normalises: scene/gaussian_model.py:137-138); entries as utils/general_utils.py:99-107. */
+static void quat_to_R(const float* q, float R[3][3]) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - r * z);
+    R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y);
+    R[2][1] = 2.f * (y * z + r * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+/* Sigma = (R S)(R S)^T, S = diag(mod * scale); six-vector [xx,xy,xz,yy,yz,zz]
+ * (scene/gaussian_model.py:28-32, utils/general_utils.py:73-85,194-207). */
+static void cov3d_from_scale_rot(const float* scale, float mod, const float* q, float* c6) {
+    float R[3][3];
+    quat_to_R(q, R);
+    float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    float L[3][3]; /* L = R * S */
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) L[i][j] = R[i][j] * s[j];
+    /* Sigma_ij = sum_k L_ik L_jk */
+    float S[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) S[i][j] = L[i][0] * L[j][0] + L[i][1] * L[j][1] + L[i][2] * L[j][2];
+    c6[0] = S[0][0]; c6[1] = S[0][1]; c6[2] = S[0][2];
+    c6[3] = S[1][1]; c6[4] = S[1][2]; c6[5] = S[2][2];
+}
+
+/* EWA projection: cov2D = (J Rv) Sigma (J Rv)^T, + 0.3 px^2 low-pass on the diagonal.
+ * Rv(i,j) = viewmatrix[j*4+i] (rotation of W2C).  Returns M = J Rv (2x3) as well, used by the
+ * backward pass. */
+static void cov2d(const float* mean, float fx, float fy, float tanfovx, float tanfovy,
+                  const float* c6, const float* V, float* cov /*a,b,c*/, float M[2][3],
+                  float* t_out /*clamped t*/, float* txtz_tytz) {
+    float t[3];
+    xform4x3(mean, V, t);
+    float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    float J00 = fx / t[2], J02 = -(fx * t[0]) / (t[2] * t[2]);
+    float J11 = fy / t[2], J12 = -(fy * t[1]) / (t[2] * t[2]);
+    for (int k = 0; k < 3; k++) {
+        /* Rv(0,k) = V[4k+0], Rv(1,k) = V[4k+1], Rv(2,k) = V[4k+2] */
+        M[0][k] = J00 * V[4 * k + 0] + J02 * V[4 * k + 2];
+        M[1][k] = J11 * V[4 * k + 1] + J12 * V[4 * k + 2];
+    }
+    float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float MS[2][3];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) MS[i][j] = M[i][0] * S[0][j] + M[i][1] * S[1][j] + M[i][2] * S[2][j];
+    cov[0] = MS[0][0] * M[0][0] + MS[0][1] * M[0][1] + MS[0][2] * M[0][2] + 0.3f;
+    cov[1] = MS[0][0] * M[1][0] + MS[0][1] * M[1][1] + MS[0][2] * M[1][2];
+    cov[2] = MS[1][0] * M[1][0] + MS[1][1] * M[1][1] + MS[1][2] * M[1][2] + 0.3f;
+    if (t_out) { t_out[0] = t[0]; t_out[1] = t[1]; t_out[2] = t[2]; }
+    if (txtz_tytz) { txtz_tytz[0] = txtz; txtz_tytz[1] = tytz; }
+}
+
+/* SH -> RGB: polynomial and constants of utils/sh_utils.py:58-101; "+0.5", clamp at 0 with the
+ * clamp recorded (models/texture/texture.py:36-37 minus its 1e-12).  shs layout (N, M, 3),
+ * coefficient-major / channel-minor (scene/gaussian_model.py:145-148). */
+static void sh_to_rgb(int deg, int M, const float* mean, const float* campos, const float* sh /*M*3*/,
+                      float* rgb, uint8_t* clamped) {
+    float d[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
+    float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+    (void)M;
+    for (int c = 0; c < 3; c++) {
+#define SH(k) sh[(k)*3 + c]
+        float r = SH_C0 * SH(0);
+        if (deg > 0) {
+            r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) +
+                    SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) + SH_C2[3] * xz * SH(7) +
+                    SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) +
+                        SH_C3[5] * z * (xx - yy) * SH(14) + SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        r += 0.5f;
+        clamped[c] = (r < 0.f);
+        rgb[c] = fmaxf(r, 0.f);
+    }
+}
+
+/* ---- A4: preprocess ---------------------------------------------------------------------- */
+/* outputs (all length P unless noted): depths f32, radii i32, xy f32[2P], conic_opacity f32[4P],
+ * rgb f32[3P], clamped u8[3P], cov3D f32[6P], tiles_touched u32, rect i32[4P] (minx,miny,maxx,maxy) */
+int or_preprocess(const OrArgs* a, float* depths, int* radii, float* xy, float* conic_opacity,
+                  float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, int* rect) {
+    const int P = a->P, W = a->W, H = a->H;
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const float fy = H / (2.0f * a->tanfovy), fx = W / (2.0f * a->tanfovx);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        radii[i] = 0;
+        tiles_touched[i] = 0;
+        depths[i] = 0.f;
+        xy[2 * i] = xy[2 * i + 1] = 0.f;
+        for (int k = 0; k < 4; k++) { conic_opacity[4 * i + k] = 0.f; rect[4 * i + k] = 0; }
+        for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0.f; clamped[3 * i + k] = 0; }
+        const float* p = a->means3D + 3 * i;
+        float pv[3];
+        xform4x3(p, a->viewmatrix, pv);
+        if (pv[2] <= 0.2f) continue; /* near cull */
+        float ph[4];
+        xform4x4(p, a->projmatrix, ph);
+        float pw = 1.0f / (ph[3] + 0.0000001f);
+        float pp[3] = {ph[0] * pw, ph[1] * pw, ph[2] * pw};
+        float* c6 = cov3D + 6 * i;
+        if (a->cov3D_precomp) {
+            for (int k = 0; k < 6; k++) c6[k] = a->cov3D_precomp[6 * i + k];
+        } else {
+            cov3d_from_scale_rot(a->scales + 3 * i, a->scale_modifier, a->rotations + 4 * i, c6);
+        }
+        float cov[3], M[2][3];
+        cov2d(p, fx, fy, a->tanfovx, a->tanfovy, c6, a->viewmatrix, cov, M, NULL, NULL);
+        float det = cov[0] * cov[2] - cov[1] * cov[1];
+        if (det == 0.0f) continue;
+        float det_inv = 1.f / det;
+        float conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
+        float mid = 0.5f * (cov[0] + cov[2]);
+        float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        float l1 = mid + sq, l2 = mid - sq;
+        float my_radius = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        /* ndc2Pix is evaluated in double upstream ((v + 1.0) * S - 1.0) * 0.5 */
+        float px = (float)((((double)pp[0] + 1.0) * (double)W - 1.0) * 0.5);
+        float py = (float)((((double)pp[1] + 1.0) * (double)H - 1.0) * 0.5);
+        int r = (int)my_radius;
+        int minx = (int)((px - r) / BLOCK_X), miny = (int)((py - r) / BLOCK_Y);
+        int maxx = (int)((px + r + BLOCK_X - 1) / BLOCK_X), maxy = (int)((py + r + BLOCK_Y - 1) / BLOCK_Y);
+        minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
+        miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
+        maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
+        maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) continue;
+        if (a->colors_precomp) {
+            for (int k = 0; k < 3; k++) rgb[3 * i + k] = a->colors_precomp[3 * i + k];
+        } else {
+            sh_to_rgb(a->deg, a->M, p, a->campos, a->shs + (size_t)i * a->M * 3, rgb + 3 * i, clamped + 3 * i);
+        }
+        depths[i] = pv[2];
+        radii[i] = r;
+        xy[2 * i] = px; xy[2 * i + 1] = py;
+        conic_opacity[4 * i + 0] = conic[0]; conic_opacity[4 * i + 1] = conic[1];
+        conic_opacity[4 * i + 2] = conic[2]; conic_opacity[4 * i + 3] = a->opacities[i];
+        tiles_touched[i] = (uint32_t)((maxy - miny) * (maxx - minx));
+        rect[4 * i + 0] = minx; rect[4 * i + 1] = miny; rect[4 * i + 2] = maxx; rect[4 * i + 3] = maxy;
+    }
+    return 0;
+}
+
+/* ---- A10: mark_visible --------------------------------------------------------------------- */
+int or_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present) {
+    for (int i = 0; i < P; i++) {
+        float pv[3];
+        xform4x3(means3D + 3 * i, viewmatrix, pv);
+        present[i] = pv[2] > 0.2f;
+    }
+    return 0;
+}
+
+/* ---- A5: scan / duplicateWithKeys / stable sort / identifyTileRanges ----------------------- */
+int64_t or_scan(int P, const uint32_t* tiles_touched, uint32_t* offsets /*inclusive*/) {
+    uint32_t acc = 0;
+    for (int i = 0; i < P; i++) { acc += tiles_touched[i]; offsets[i] = acc; }
+    return P > 0 ? (int64_t)acc : 0;
+}
+
+void or_duplicate_with_keys(int P, int W, const float* depths, const int* radii, const int* rect,
+                            const uint32_t* offsets, uint64_t* keys, uint32_t* vals) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X;
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        uint32_t off = (i == 0) ? 0 : offsets[i - 1];
+        uint32_t dbits;
+        memcpy(&dbits, &depths[i], 4);
+        for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; y++)
+            for (int x = rect[4 * i + 0]; x < rect[4 * i + 2]; x++) {
+                uint64_t key = (uint64_t)(y * gx + x);
+                key <<= 32;
+                key |= dbits;
+                keys[off] = key;
+                vals[off] = (uint32_t)i;
+                off++;
+            }
+    }
+}
+
+typedef struct { uint64_t k; uint32_t v; uint32_t pos; } KV;
+static int kv_cmp(const void* a, const void* b) {
+    const KV* x = (const KV*)a; const KV* y = (const KV*)b;
+    if (x->k != y->k) return x->k < y->k ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0); /* stable */
+}
+int or_sort_pairs(int64_t D, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout) {
+    KV* t = (KV*)malloc(sizeof(KV) * (size_t)(D > 0 ? D : 1));
+    if (!t) return -1;
+    for (int64_t j = 0; j < D; j++) { t[j].k = kin[j]; t[j].v = vin[j]; t[j].pos = (uint32_t)j; }
+    qsort(t, (size_t)D, sizeof(KV), kv_cmp);
+    for (int64_t j = 0; j < D; j++) { kout[j] = t[j].k; vout[j] = t[j].v; }
+    free(t);
+    return 0;
+}
+
+void or_tile_ranges(int64_t D, const uint64_t* keys, int ntiles, uint32_t* ranges /*ntiles*2*/) {
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles);
+    for (int64_t j = 0; j < D; j++) {
+        uint32_t cur = (uint32_t)(keys[j] >> 32);
+        if (j == 0) ranges[2 * cur] = 0;
+        else {
+            uint32_t prev = (uint32_t)(keys[j - 1] >> 32);
+            if (cur != prev) { ranges[2 * prev + 1] = (uint32_t)j; ranges[2 * cur] = (uint32_t)j; }
+        }
+        if (j == D - 1) ranges[2 * cur + 1] = (uint32_t)D;
+    }
+}
+
+/* ---- A6: render forward --------------------------------------------------------------------- */
+int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                      float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                float pxf = (float)pxi, pyf = (float)pyi;
+                float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
+                uint32_t contributor = 0, last = 0;
+                for (uint32_t j = r0; j < r1; j++) {
+                    contributor++;
+                    uint32_t g = point_list[j];
+                    float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+                    const float* co = conic_opacity + 4 * g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf(0.99f, co[3] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break; /* done: this Gaussian is NOT blended */
+                    for (int c = 0; c < 3; c++) C[c] += rgb[3 * g + c] * alpha * T;
+                    T = test_T;
+                    last = contributor;
+                }
+                size_t pid = (size_t)pyi * W + pxi;
+                final_T[pid] = T;
+                n_contrib[pid] = last;
+                for (int c = 0; c < 3; c++) out_color[(size_t)c * H * W + pid] = C[c] + T * bg[c];
+            }
+    }
+    return 0;
+}
+
+/* ---- A7: render backward -------------------------------------------------------------------- */
+/* Back-to-front per pixel with T recovered by division, exactly the recurrence of the reference
+ * kernel; the nine per-Gaussian sums are accumulated in double per list entry, then folded per
+ * Gaussian in list order.  Outputs (double): dL_dmean2D[2P], dL_dconic[3P] (A,B,C), dL_dopacity[P],
+ * dL_dcolor[3P]. */
+int or_render_backward(int P, int W, int H, int64_t D, const uint32_t* ranges, const uint32_t* point_list,
+                       const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                       const float* final_T, const uint32_t* n_contrib, const float* dL_dpix /*3HW*/,
+                       double* dL_dmean2D, double* dL_dconic, double* dL_dopacity, double* dL_dcolor) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    double* E = (double*)calloc((size_t)(D > 0 ? D : 1) * 9, sizeof(double));
+    if (!E) return -1;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                size_t pid = (size_t)pyi * W + pxi;
+                float pxf = (float)pxi, pyf = (float)pyi;
+                const float T_final = final_T[pid];
+                float T = T_final;
+                uint32_t contributor = r1 - r0;
+                const uint32_t last_contributor = n_contrib[pid];
+                float accum_rec[3] = {0, 0, 0}, dLp[3], last_color[3] = {0, 0, 0};
+                for (int c = 0; c < 3; c++) dLp[c] = dL_dpix[(size_t)c * H * W + pid];
+                float last_alpha = 0.f;
+                for (uint32_t jj = r1; jj > r0; jj--) {
+                    uint32_t j = jj - 1;
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    uint32_t g = point_list[j];
+                    float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+                    const float* co = conic_opacity + 4 * g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float G = expf(power);
+                    float alpha = fminf(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    double* e = E + (size_t)j * 9;
+                    for (int c = 0; c < 3; c++) {
+                        float col = rgb[3 * g + c];
+                        accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
+                        last_color[c] = col;
+                        dL_dalpha += (col - accum_rec[c]) * dLp[c];
+                        e[6 + c] += (double)(dchannel_dcolor * dLp[c]);
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    float bg_dot = 0.f;
+                    for (int c = 0; c < 3; c++) bg_dot += bg[c] * dLp[c];
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    float dL_dG = co[3] * dL_dalpha;
+                    float gdx = G * dx, gdy = G * dy;
+                    float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    e[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    e[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    e[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                    e[3] += (double)(-0.5f * gdx * dy * dL_dG);
+                    e[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                    e[5] += (double)(G * dL_dalpha);
+                }
+            }
+    }
+    memset(dL_dmean2D, 0, sizeof(double) * 2 * (size_t)P);
+    memset(dL_dconic, 0, sizeof(double) * 3 * (size_t)P);
+    memset(dL_dopacity, 0, sizeof(double) * (size_t)P);
+    memset(dL_dcolor, 0, sizeof(double) * 3 * (size_t)P);
+    for (int64_t j = 0; j < D; j++) {
+        uint32_t g = point_list[j];
+        const double* e = E + (size_t)j * 9;
+        dL_dmean2D[2 * g] += e[0]; dL_dmean2D[2 * g + 1] += e[1];
+        dL_dconic[3 * g] += e[2]; dL_dconic[3 * g + 1] += e[3]; dL_dconic[3 * g + 2] += e[4];
+        dL_dopacity[g] += e[5];
+        dL_dcolor[3 * g] += e[6]; dL_dcolor[3 * g + 1] += e[7]; dL_dcolor[3 * g + 2] += e[8];
+    }
+    free(E);
+    return 0;
+}
+
+/* ---- A8: preprocess backward ---------------------------------------------------------------- */
+/* Inputs: per-Gaussian 2-D gradients (float, as the HIP path would hold them) and the forward
+ * state (radii, cov3D, clamped).  Outputs: dL_dmeans3D[3P], dL_dsh[P*M*3], dL_dcov3D[6P],
+ * dL_dscale[3P], dL_drot[4P] -- all written in full (zeros where radii <= 0). */
+int or_preprocess_backward(const OrArgs* a, const int* radii, const float* cov3D, const uint8_t* clamped,
+                           const float* dL_dmean2D /*2P*/, const float* dL_dconic /*3P*/,
+                           const float* dL_dcolor /*3P*/, float* dL_dmeans3D, float* dL_dsh,
+                           float* dL_dcov3D, float* dL_dscale, float* dL_drot) {
+    const int P = a->P, W = a->W, H = a->H, M = a->M;
+    const float fy = H / (2.0f * a->tanfovy), fx = W / (2.0f * a->tanfovx);
+    const float* V = a->viewmatrix;
+    const float* proj = a->projmatrix;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        float* gm = dL_dmeans3D + 3 * i;
+        gm[0] = gm[1] = gm[2] = 0.f;
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+        if (dL_dsh) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
+        if (dL_dscale) for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = 0.f;
+        if (dL_drot) for (int k = 0; k < 4; k++) dL_drot[4 * i + k] = 0.f;
+        if (!(radii[i] > 0)) continue;
+        const float* mean = a->means3D + 3 * i;
+        const float* c6 = cov3D + 6 * i;
+        /* (i) conic -> cov2D, (ii) cov2D -> cov3D, (iii) cov2D -> mean through J */
+        float cov[3], Mx[2][3], t[3], tt[2];
+        cov2d(mean, fx, fy, a->tanfovx, a->tanfovy, c6, V, cov, Mx, t, tt);
+        const float limx = 1.3f * a->tanfovx, limy = 1.3f * a->tanfovy;
+        const float x_grad_mul = (tt[0] < -limx || tt[0] > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tt[1] < -limy || tt[1] > limy) ? 0.f : 1.f;
+        float ca = cov[0], cb = cov[1], cc = cov[2];
+        float gA = dL_dconic[3 * i], gB = dL_dconic[3 * i + 1], gC = dL_dconic[3 * i + 2];
+        float denom = ca * cc - cb * cb;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float* gc = dL_dcov3D + 6 * i;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * gA + 2 * cb * cc * gB + (denom - ca * cc) * gC);
+            dL_dc = denom2inv * (-ca * ca * gC + 2 * ca * cb * gB + (denom - ca * cc) * gA);
+            dL_db = denom2inv * 2 * (cb * cc * gA - (denom + 2 * cb * cb) * gB + ca * cb * gC);
+            const float* m0 = Mx[0]; const float* m1 = Mx[1];
+            gc[0] = (m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc);
+            gc[3] = (m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc);
+            gc[5] = (m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc);
+            gc[1] = 2 * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2 * m1[0] * m1[1] * dL_dc;
+            gc[2] = 2 * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2 * m1[0] * m1[2] * dL_dc;
+            gc[4] = 2 * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2 * m1[1] * m1[2] * dL_dc;
+        }
+        float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float dM[2][3];
+        for (int k = 0; k < 3; k++) {
+            float m0S = Mx[0][0] * S[k][0] + Mx[0][1] * S[k][1] + Mx[0][2] * S[k][2];
+            float m1S = Mx[1][0] * S[k][0] + Mx[1][1] * S[k][1] + Mx[1][2] * S[k][2];
+            dM[0][k] = 2 * m0S * dL_da + m1S * dL_db;
+            dM[1][k] = 2 * m1S * dL_dc + m0S * dL_db;
+        }
+        /* M = J Rv, Rv(i,k) = V[4k+i] */
+        float dJ00 = V[0] * dM[0][0] + V[4] * dM[0][1] + V[8] * dM[0][2];
+        float dJ02 = V[2] * dM[0][0] + V[6] * dM[0][1] + V[10] * dM[0][2];
+        float dJ11 = V[1] * dM[1][0] + V[5] * dM[1][1] + V[9] * dM[1][2];
+        float dJ12 = V[2] * dM[1][0] + V[6] * dM[1][1] + V[10] * dM[1][2];
+        float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        float dtx = x_grad_mul * -fx * tz2 * dJ02;
+        float dty = y_grad_mul * -fy * tz2 * dJ12;
+        float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * t[0]) * tz3 * dJ02 + (2 * fy * t[1]) * tz3 * dJ12;
+        gm[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+        gm[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+        gm[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+        /* (iv) mean2D -> mean3D through the perspective divide */
+        float mh[4];
+        xform4x4(mean, proj, mh);
+        float mw = 1.0f / (mh[3] + 0.0000001f);
+        float mul1 = (proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12]) * mw * mw;
+        float mul2 = (proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13]) * mw * mw;
+        float g2x = dL_dmean2D[2 * i], g2y = dL_dmean2D[2 * i + 1];
+        gm[0] += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
+        gm[1] += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
+        gm[2] += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
+        /* (v) SH backward */
+        if (a->shs) {
+            const float* sh = a->shs + (size_t)i * M * 3;
+            float* gsh = dL_dsh + (size_t)i * M * 3;
+            float dor[3] = {mean[0] - a->campos[0], mean[1] - a->campos[1], mean[2] - a->campos[2]};
+            float len = sqrtf(dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2]);
+            float x = dor[0] / len, y = dor[1] / len, z = dor[2] / len;
+            float gR[3];
+            for (int c = 0; c < 3; c++) gR[c] = clamped[3 * i + c] ? 0.f : dL_dcolor[3 * i + c];
+            float ddir[3] = {0, 0, 0};
+            const int deg = a->deg;
+            for (int c = 0; c < 3; c++) {
+#define SH(k) sh[(k)*3 + c]
+#define GSH(k) gsh[(k)*3 + c]
+                float dx = 0, dy = 0, dz = 0;
+                GSH(0) = SH_C0 * gR[c];
+                if (deg > 0) {
+                    GSH(1) = -SH_C1 * y * gR[c]; GSH(2) = SH_C1 * z * gR[c]; GSH(3) = -SH_C1 * x * gR[c];
+                    dx = -SH_C1 * SH(3); dy = -SH_C1 * SH(1); dz = SH_C1 * SH(2);
+                    if (deg > 1) {
+                        float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+                        GSH(4) = SH_C2[0] * xy_ * gR[c]; GSH(5) = SH_C2[1] * yz * gR[c];
+                        GSH(6) = SH_C2[2] * (2.f * zz - xx - yy) * gR[c];
+                        GSH(7) = SH_C2[3] * xz * gR[c]; GSH(8) = SH_C2[4] * (xx - yy) * gR[c];
+                        dx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                        dy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                        dz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                        if (deg > 2) {
+                            GSH(9) = SH_C3[0] * y * (3.f * xx - yy) * gR[c];
+                            GSH(10) = SH_C3[1] * xy_ * z * gR[c];
+                            GSH(11) = SH_C3[2] * y * (4.f * zz - xx - yy) * gR[c];
+                            GSH(12) = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gR[c];
+                            GSH(13) = SH_C3[4] * x * (4.f * zz - xx - yy) * gR[c];
+                            GSH(14) = SH_C3[5] * z * (xx - yy) * gR[c];
+                            GSH(15) = SH_C3[6] * x * (xx - 3.f * yy) * gR[c];
+                            dx += SH_C3[0] * SH(9) * 3.f * 2.f * xy_ + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy_ +
+                                  SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
+                            dy += SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                                  SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy_ +
+                                  SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy_;
+                            dz += SH_C3[1] * SH(10) * xy_ + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                                  SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy);
+                        }
+                    }
+                }
+#undef SH
+#undef GSH
+                ddir[0] += dx * gR[c]; ddir[1] += dy * gR[c]; ddir[2] += dz * gR[c];
+            }
+            /* through dir = v/|v| */
+            float sum2 = dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2];
+            float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            gm[0] += ((+sum2 - dor[0] * dor[0]) * ddir[0] - dor[1] * dor[0] * ddir[1] - dor[2] * dor[0] * ddir[2]) * invsum32;
+            gm[1] += (-dor[0] * dor[1] * ddir[0] + (sum2 - dor[1] * dor[1]) * ddir[1] - dor[2] * dor[1] * ddir[2]) * invsum32;
+            gm[2] += (-dor[0] * dor[2] * ddir[0] - dor[1] * dor[2] * ddir[1] + (sum2 - dor[2] * dor[2]) * ddir[2]) * invsum32;
+        }
+        /* (vi) cov3D -> scale, rotation.  Sigma = L L^T, L = R S.  As in the reference kernel the
+         * scale gradient is taken w.r.t. s = mod*scale and NOT multiplied by mod (exact for
+         * mod = 1, the only value the reference passes: gaussian_renderer/__init__.py:64). */
+        if (a->scales) {
+            const float* q = a->rotations + 4 * i;
+            float R[3][3];
+            quat_to_R(q, R);
+            float s[3] = {a->scale_modifier * a->scales[3 * i], a->scale_modifier * a->scales[3 * i + 1],
+                          a->scale_modifier * a->scales[3 * i + 2]};
+            /* dL/dSigma symmetric with halved off-diagonals (six-vector carries the x2) */
+            float dS[3][3] = {{gc[0], 0.5f * gc[1], 0.5f * gc[2]},
+                              {0.5f * gc[1], gc[3], 0.5f * gc[4]},
+                              {0.5f * gc[2], 0.5f * gc[4], gc[5]}};
+            /* dL/dL = 2 dS L, L = R diag(s) */
+            float L[3][3], dL[3][3];
+            for (int r_ = 0; r_ < 3; r_++) for (int c_ = 0; c_ < 3; c_++) L[r_][c_] = R[r_][c_] * s[c_];
+            for (int r_ = 0; r_ < 3; r_++)
+                for (int c_ = 0; c_ < 3; c_++)
+                    dL[r_][c_] = 2.0f * (dS[r_][0] * L[0][c_] + dS[r_][1] * L[1][c_] + dS[r_][2] * L[2][c_]);
+            /* dL/ds_c = sum_r R[r][c] dL[r][c];  dL/dR[r][c] = dL[r][c] s_c */
+            float dR[3][3];
+            for (int c_ = 0; c_ < 3; c_++) {
+                dL_dscale[3 * i + c_] = R[0][c_] * dL[0][c_] + R[1][c_] * dL[1][c_] + R[2][c_] * dL[2][c_];
+                for (int r_ = 0; r_ < 3; r_++) dR[r_][c_] = dL[r_][c_] * s[c_];
+            }
+            float r = q[0], x = q[1], y = q[2], z = q[3];
+            float* gq = dL_drot + 4 * i;
+            gq[0] = 2 * z * (dR[1][0] - dR[0][1]) + 2 * y * (dR[0][2] - dR[2][0]) + 2 * x * (dR[2][1] - dR[1][2]);
+            gq[1] = 2 * y * (dR[0][1] + dR[1][0]) + 2 * z * (dR[0][2] + dR[2][0]) + 2 * r * (dR[2][1] - dR[1][2]) - 4 * x * (dR[2][2] + dR[1][1]);
+            gq[2] = 2 * x * (dR[0][1] + dR[1][0]) + 2 * r * (dR[0][2] - dR[2][0]) + 2 * z * (dR[2][1] + dR[1][2]) - 4 * y * (dR[2][2] + dR[0][0]);
+            gq[3] = 2 * r * (dR[1][0] - dR[0][1]) + 2 * x * (dR[0][2] + dR[2][0]) + 2 * y * (dR[2][1] + dR[1][2]) - 4 * z * (dR[1][1] + dR[0][0]);
+        }
+    }
+    return 0;
+}
+
+/* ---- A9: distCUDA2 --------------------------------------------------------------------------- */
+/* Exact mean of the squared distances to the 3 nearest OTHER points (self excluded by index, so
+ * duplicated points give 0 and the caller's clamp 1e-7 applies: scene/gaussian_model.py:186).
+ * Brute force O(N^2); distance d.x*d.x + d.y*d.y + d.z*d.z in fp32, best-3 kept ascending,
+ * result (b0 + b1 + b2) / 3.0f. */
+int or_dist2(int P, const float* pts, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+        const float* p = pts + 3 * i;
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            float dx = p[0] - pts[3 * j], dy = p[1] - pts[3 * j + 1], dz = p[2] - pts[3 * j + 2];
+            float d = dx * dx + dy * dy + dz * dz;
+            for (int k = 0; k < 3; k++)
+                if (best[k] > d) { float tmp = best[k]; best[k] = d; d = tmp; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+    return 0;
+}
+
+int or_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,214 @@
+"""ctypes front-end of the CPU oracle (oracle/gs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg as the checker / reported baseline.  The shipped package never imports this module.
+PARITY UNPINNED (see the header of gs_oracle.c): the reference tree holds neither source nor
+golden vectors for the rasterizer; the pieces it does pin (SH polynomial, camera matrices) are
+checked against fixtures in tests/golden/.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_double, c_float, c_int, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgs_oracle.so")
+
+
+class OrArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", c_int), ("deg", c_int), ("M", c_int), ("W", c_int), ("H", c_int),
+        ("bg", c_void_p), ("means3D", c_void_p), ("shs", c_void_p), ("colors_precomp", c_void_p),
+        ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p),
+        ("cov3D_precomp", c_void_p), ("viewmatrix", c_void_p), ("projmatrix", c_void_p),
+        ("campos", c_void_p),
+        ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
+        ("prefiltered", c_int),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/gs_oracle.c with gcc (strict fp32, OpenMP)."""
+    src = os.path.join(_HERE, "gs_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.or_scan.restype = c_int64
+    return _lib
+
+
+def _f32(x):
+    return None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+class Scene(object):
+    """Plain container of the rasterizer inputs as float32 numpy arrays (None = absent, mirroring
+    the reference wrapper's empty-tensor convention, gaussian_renderer/__init__.py:107-129)."""
+
+    def __init__(self, W, H, tanfovx, tanfovy, bg, viewmatrix, projmatrix, campos, means3D, opacities,
+                 shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                 sh_degree=0, scale_modifier=1.0, prefiltered=False):
+        self.W, self.H = int(W), int(H)
+        self.tanfovx, self.tanfovy = float(tanfovx), float(tanfovy)
+        self.bg = _f32(bg).reshape(3)
+        self.viewmatrix = _f32(viewmatrix).reshape(16)
+        self.projmatrix = _f32(projmatrix).reshape(16)
+        self.campos = _f32(campos).reshape(3)
+        self.means3D = _f32(means3D).reshape(-1, 3)
+        self.P = self.means3D.shape[0]
+        self.opacities = _f32(opacities).reshape(self.P)
+        self.shs = _f32(shs)
+        self.colors_precomp = _f32(colors_precomp)
+        self.scales = _f32(scales)
+        self.rotations = _f32(rotations)
+        self.cov3D_precomp = _f32(cov3D_precomp)
+        self.sh_degree = int(sh_degree)
+        self.M = 0 if self.shs is None else int(self.shs.shape[1])
+        self.scale_modifier = float(scale_modifier)
+        self.prefiltered = bool(prefiltered)
+        if (self.shs is None) == (self.colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((self.scales is None or self.rotations is None) and self.cov3D_precomp is None) or \
+                ((self.scales is not None or self.rotations is not None) and self.cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+    def cargs(self):
+        a = OrArgs()
+        a.P, a.deg, a.M, a.W, a.H = self.P, self.sh_degree, self.M, self.W, self.H
+        a.bg, a.means3D, a.shs = _ptr(self.bg), _ptr(self.means3D), _ptr(self.shs)
+        a.colors_precomp, a.opacities = _ptr(self.colors_precomp), _ptr(self.opacities)
+        a.scales, a.rotations, a.cov3D_precomp = _ptr(self.scales), _ptr(self.rotations), _ptr(self.cov3D_precomp)
+        a.viewmatrix, a.projmatrix, a.campos = _ptr(self.viewmatrix), _ptr(self.projmatrix), _ptr(self.campos)
+        a.scale_modifier, a.tanfovx, a.tanfovy = self.scale_modifier, self.tanfovx, self.tanfovy
+        a.prefiltered = int(self.prefiltered)
+        return a
+
+
+def preprocess(sc):
+    P = sc.P
+    st = dict(
+        depths=np.zeros(P, np.float32), radii=np.zeros(P, np.int32), xy=np.zeros((P, 2), np.float32),
+        conic_opacity=np.zeros((P, 4), np.float32), rgb=np.zeros((P, 3), np.float32),
+        clamped=np.zeros((P, 3), np.uint8), cov3D=np.zeros((P, 6), np.float32),
+        tiles_touched=np.zeros(P, np.uint32), rect=np.zeros((P, 4), np.int32))
+    a = sc.cargs()
+    rc = lib().or_preprocess(ctypes.byref(a), _ptr(st["depths"]), _ptr(st["radii"]), _ptr(st["xy"]),
+                             _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(st["clamped"]),
+                             _ptr(st["cov3D"]), _ptr(st["tiles_touched"]), _ptr(st["rect"]))
+    assert rc == 0
+    return st
+
+
+def binning(sc, st):
+    """A5: inclusive scan, duplicateWithKeys, stable sort, identifyTileRanges."""
+    P = sc.P
+    L = lib()
+    offsets = np.zeros(P, np.uint32)
+    D = int(L.or_scan(c_int(P), _ptr(st["tiles_touched"]), _ptr(offsets)))
+    keys_u = np.zeros(max(D, 1), np.uint64)
+    vals_u = np.zeros(max(D, 1), np.uint32)
+    L.or_duplicate_with_keys(c_int(P), c_int(sc.W), _ptr(st["depths"]), _ptr(st["radii"]), _ptr(st["rect"]),
+                             _ptr(offsets), _ptr(keys_u), _ptr(vals_u))
+    keys = np.zeros(max(D, 1), np.uint64)
+    vals = np.zeros(max(D, 1), np.uint32)
+    rc = L.or_sort_pairs(c_int64(D), _ptr(keys_u), _ptr(vals_u), _ptr(keys), _ptr(vals))
+    assert rc == 0
+    gx, gy = (sc.W + 15) // 16, (sc.H + 15) // 16
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    L.or_tile_ranges(c_int64(D), _ptr(keys), c_int(gx * gy), _ptr(ranges))
+    return dict(offsets=offsets, D=D, keys_unsorted=keys_u[:D], vals_unsorted=vals_u[:D],
+                keys=keys[:D], point_list=vals[:D], ranges=ranges)
+
+
+def render_forward(sc, st, bn):
+    W, H = sc.W, sc.H
+    out = np.zeros((3, H, W), np.float32)
+    final_T = np.zeros((H, W), np.float32)
+    n_contrib = np.zeros((H, W), np.uint32)
+    pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
+    rc = lib().or_render_forward(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
+                                 _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
+                                 _ptr(out), _ptr(final_T), _ptr(n_contrib))
+    assert rc == 0
+    return dict(color=out, final_T=final_T, n_contrib=n_contrib)
+
+
+def forward(sc):
+    """Full forward: returns (color[3,H,W], radii[P]) plus every intermediate."""
+    st = preprocess(sc)
+    bn = binning(sc, st)
+    im = render_forward(sc, st, bn)
+    return dict(geom=st, binning=bn, image=im, color=im["color"], radii=st["radii"])
+
+
+def backward(sc, fw, dL_dpix):
+    """Full backward for dL/dcolor = dL_dpix[3,H,W]; returns the eight gradient tensors of the
+    reference wrapper (A3) plus the per-Gaussian 2-D intermediates."""
+    P, W, H = sc.P, sc.W, sc.H
+    st, bn, im = fw["geom"], fw["binning"], fw["image"]
+    g = np.ascontiguousarray(np.asarray(dL_dpix, np.float32).reshape(3, H, W))
+    d_mean2D = np.zeros((P, 2), np.float64)
+    d_conic = np.zeros((P, 3), np.float64)
+    d_op = np.zeros(P, np.float64)
+    d_col = np.zeros((P, 3), np.float64)
+    pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
+    rc = lib().or_render_backward(c_int(P), c_int(W), c_int(H), c_int64(bn["D"]), _ptr(bn["ranges"]), _ptr(pl),
+                                  _ptr(st["xy"]), _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
+                                  _ptr(im["final_T"]), _ptr(im["n_contrib"]), _ptr(g),
+                                  _ptr(d_mean2D), _ptr(d_conic), _ptr(d_op), _ptr(d_col))
+    assert rc == 0
+    m2 = d_mean2D.astype(np.float32)
+    cn = d_conic.astype(np.float32)
+    cl = d_col.astype(np.float32)
+    d_means3D = np.zeros((P, 3), np.float32)
+    d_cov3D = np.zeros((P, 6), np.float32)
+    d_sh = np.zeros((P, sc.M, 3), np.float32) if sc.shs is not None else None
+    d_scale = np.zeros((P, 3), np.float32) if sc.scales is not None else None
+    d_rot = np.zeros((P, 4), np.float32) if sc.scales is not None else None
+    a = sc.cargs()
+    rc = lib().or_preprocess_backward(ctypes.byref(a), _ptr(st["radii"]), _ptr(st["cov3D"]), _ptr(st["clamped"]),
+                                      _ptr(m2), _ptr(cn), _ptr(cl), _ptr(d_means3D), _ptr(d_sh),
+                                      _ptr(d_cov3D), _ptr(d_scale), _ptr(d_rot))
+    assert rc == 0
+    d_means2D = np.zeros((P, 3), np.float32)
+    d_means2D[:, :2] = m2
+    return dict(means3D=d_means3D, means2D=d_means2D, sh=d_sh, colors_precomp=cl,
+                opacities=d_op.astype(np.float32).reshape(P, 1), scales=d_scale, rotations=d_rot,
+                cov3D_precomp=d_cov3D, conic=cn)
+
+
+def mark_visible(means3D, viewmatrix):
+    m = _f32(means3D).reshape(-1, 3)
+    v = _f32(viewmatrix).reshape(16)
+    out = np.zeros(m.shape[0], np.uint8)
+    lib().or_mark_visible(c_int(m.shape[0]), _ptr(m), _ptr(v), _ptr(out))
+    return out.astype(bool)
+
+
+def dist2(points):
+    """A9 restatement: exact brute-force mean squared distance to the 3 nearest other points."""
+    p = _f32(points).reshape(-1, 3)
+    out = np.zeros(p.shape[0], np.float32)
+    lib().or_dist2(c_int(p.shape[0]), _ptr(p), _ptr(out))
+    return out
+
+
+def num_threads():
+    return int(lib().or_num_threads())

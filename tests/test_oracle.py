@@ -1,0 +1,257 @@
+"""Self-checks of the CPU oracle (oracle/gs_oracle.c): closed forms, structural invariants, and every
+analytic backward formula against float64 autograd of an independent dense restatement
+(oracle/dense_ref.py).  The reference holds no tests or vectors for this path, so
+these are what pins the oracle; see DESIGN.md "parity unpinned"."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from gsplat_mi355.camera import Camera, focal2fov
+
+
+def _single(oracle, W=64, H=64, pos=(0.0, 0.0, 0.0), sigma=0.05, opacity=0.8, rgb=(0.2, 0.5, 0.9), bg=(0.1, 0.2, 0.3),
+            z=3.0):
+    f = 500.0 * W / 512.0
+    cam = Camera(np.eye(3), np.array([0.0, 0.0, z]), focal2fov(f, W), focal2fov(f, H), W, H)
+    sc = oracle.Scene(W, H, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), np.array(bg, np.float32),
+                      cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), cam.camera_center.numpy(),
+                      np.array([pos], np.float32), np.array([opacity], np.float32),
+                      colors_precomp=np.array([rgb], np.float32), scales=np.full((1, 3), sigma, np.float32),
+                      rotations=np.array([[1, 0, 0, 0]], np.float32))
+    return sc, cam, f
+
+
+def test_closed_form_single_isotropic_gaussian(oracle):
+    W = H = 64
+    # centre the Gaussian exactly on pixel (32, 20): ndc = (2*px + 1)/W - 1
+    z = 3.0
+    f = 500.0 * W / 512.0
+    px, py = 32, 20
+    x = ((2 * px + 1) / W - 1) * (W / (2 * f)) * z
+    y = ((2 * py + 1) / H - 1) * (H / (2 * f)) * z
+    sc, cam, f = _single(oracle, W, H, pos=(x, y, 0.0), z=z)
+    fw = oracle.forward(sc)
+    st = fw["geom"]
+    assert abs(st["xy"][0, 0] - px) < 1e-3 and abs(st["xy"][0, 1] - py) < 1e-3
+    s2 = (f * 0.05 / z) ** 2 + 0.3  # cov2D = (fx sigma / z)^2 I + 0.3 I near the optical axis
+    lam = 1.0 / st["conic_opacity"][0, 0]
+    assert abs(lam - s2) / s2 < 2e-2  # off-axis Jacobian terms are second order
+    assert st["radii"][0] == math.ceil(3 * math.sqrt(max(1.0 / st["conic_opacity"][0, 0], 1.0 / st["conic_opacity"][0, 2])) - 1e-4) or \
+        st["radii"][0] == math.ceil(3 * math.sqrt(s2))
+    a = min(0.99, 0.8)
+    got = fw["color"][:, py, px]
+    want = a * np.array([0.2, 0.5, 0.9]) + (1 - a) * np.array([0.1, 0.2, 0.3])
+    assert np.abs(got - want).max() < 2e-5
+    assert abs(fw["image"]["final_T"][py, px] - (1 - a)) < 1e-6
+    assert fw["image"]["n_contrib"][py, px] == 1
+    # far corner: only background
+    assert np.abs(fw["color"][:, 0, 0] - np.array([0.1, 0.2, 0.3])).max() < 1e-7
+
+
+def test_near_plane_cull_at_0p2(oracle):
+    for zc, expect in [(0.2, False), (0.2001, True), (0.1, False), (-1.0, False)]:
+        sc, cam, f = _single(oracle, pos=(0, 0, zc), sigma=0.001, z=0.0)  # z_view == zc exactly
+        st = oracle.preprocess(sc)
+        assert (st["radii"][0] > 0) == expect, zc
+        assert oracle.mark_visible(sc.means3D, sc.viewmatrix)[0] == expect
+        if not expect:
+            assert st["tiles_touched"][0] == 0
+
+
+def test_two_gaussians_blend_is_depth_ordered(oracle):
+    W = H = 32
+    f = 500.0 * W / 512.0
+    cam = Camera(np.eye(3), np.array([0.0, 0.0, 3.0]), focal2fov(f, W), focal2fov(f, H), W, H)
+    x = ((2 * 16 + 1) / W - 1) * (W / (2 * f))
+    cols = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    res = []
+    for zs in [(0.0, 0.5), (0.5, 0.0)]:
+        means = np.array([[x * (3 + zs[0]), x * (3 + zs[0]), zs[0]], [x * (3 + zs[1]), x * (3 + zs[1]), zs[1]]], np.float32)
+        sc = oracle.Scene(W, H, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), np.zeros(3),
+                          cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), cam.camera_center.numpy(),
+                          means, np.array([0.6, 0.6], np.float32), colors_precomp=cols,
+                          scales=np.full((2, 3), 0.3, np.float32), rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (2, 1)))
+        res.append(oracle.forward(sc)["color"][:, 16, 16])
+    # front Gaussian dominates: red in the first arrangement, green in the second
+    assert res[0][0] > res[0][1] and res[1][1] > res[1][0]
+    assert abs(res[0][0] - 0.6) < 1e-2 and abs(res[0][1] - 0.4 * 0.6) < 1e-2
+
+
+@pytest.mark.parametrize("n,W,H", [(1500, 96, 64), (400, 40, 40)])
+def test_structural_invariants(oracle, n, W, H):
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=3)
+    sc = helpers.oracle_scene(cloud, cam, bg=(0.2, 0.1, 0.0))
+    fw = oracle.forward(sc)
+    st, bn, im = fw["geom"], fw["binning"], fw["image"]
+    D = bn["D"]
+    assert D == int(st["tiles_touched"].astype(np.int64).sum()) == len(bn["point_list"])
+    keys = bn["keys"]
+    assert (np.diff(keys.astype(np.uint64)) >= 0).all() if D > 1 else True
+    # ranges partition [0, D) over the non-empty tiles
+    r = bn["ranges"]
+    nz = r[:, 1] > r[:, 0]
+    assert int((r[nz, 1] - r[nz, 0]).sum()) == D
+    starts = np.sort(r[nz, 0])
+    ends = np.sort(r[nz, 1])
+    assert starts[0] == 0 and ends[-1] == D and (starts[1:] == ends[:-1]).all()
+    # within a tile: depth non-decreasing, ties in ascending Gaussian index
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    depth_bits = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    same = tiles[1:] == tiles[:-1]
+    tie = same & (depth_bits[1:] == depth_bits[:-1])
+    assert (bn["point_list"][1:][tie] > bn["point_list"][:-1][tie]).all()
+    assert (st["depths"][bn["point_list"]].view(np.uint32) == depth_bits).all()
+    # culled => radii 0, tiles 0
+    culled = st["radii"] == 0
+    assert (st["tiles_touched"][culled] == 0).all()
+    # image - T*bg >= 0
+    bgv = np.array([0.2, 0.1, 0.0], np.float32)[:, None, None]
+    assert (fw["color"] - im["final_T"][None] * bgv >= -1e-6).all()
+    # n_contrib never exceeds the tile's list length
+    gx = (W + 15) // 16
+    for ty in range((H + 15) // 16):
+        for tx in range(gx):
+            t = ty * gx + tx
+            blk = im["n_contrib"][ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
+            assert blk.max() <= r[t, 1] - r[t, 0]
+
+
+def test_opacity_render_is_one_minus_T_for_black_bg(oracle):
+    cloud, cam = helpers.cloud_and_camera(800, 64, 64, seed=5)
+    ones = torch.ones(cloud.num, 3)
+    sc = helpers.oracle_scene(cloud, cam, color_mode="precomp", colors=ones)
+    fw = oracle.forward(sc)
+    assert np.abs(fw["color"][0] - (1 - fw["image"]["final_T"])).max() < 2e-6
+
+
+def test_permutation_invariance(oracle):
+    cloud, cam = helpers.cloud_and_camera(700, 64, 48, seed=7)
+    sc = helpers.oracle_scene(cloud, cam)
+    a = oracle.forward(sc)["color"]
+    perm = torch.randperm(cloud.num, generator=torch.Generator().manual_seed(1))
+    from gsplat_mi355.scenes import GaussianCloud
+    c2 = GaussianCloud(cloud.xyz[perm], cloud.scales[perm], cloud.rotations[perm], cloud.opacity[perm], cloud.shs[perm],
+                       cloud.sh_degree)
+    b = oracle.forward(helpers.oracle_scene(c2, cam))["color"]
+    assert np.abs(a - b).max() < 1e-6  # random depths: no ties, order fully determined
+
+
+def _dense_grads(sc, cloud, cam, gimg, color_mode, cov_mode, bg, scale_modifier=1.0, colors=None):
+    from oracle import dense_ref
+    dt = torch.float64
+    t = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dt)
+    leaves = {}
+
+    def leaf(name, arr):
+        v = t(arr).clone().requires_grad_(True)
+        leaves[name] = v
+        return v
+    means3D = leaf("means3D", sc.means3D)
+    means2D = leaf("means2D", np.zeros((sc.P, 3)))
+    opac = leaf("opacities", sc.opacities.reshape(-1, 1))
+    kw = {}
+    if color_mode == "sh":
+        kw["shs"] = leaf("sh", sc.shs)
+        kw["sh_degree"] = sc.sh_degree
+    else:
+        kw["colors_precomp"] = leaf("colors_precomp", sc.colors_precomp)
+    if cov_mode == "scale_rot":
+        kw["scales"] = leaf("scales", sc.scales)
+        kw["rotations"] = leaf("rotations", sc.rotations)
+    else:
+        kw["cov3D_precomp"] = leaf("cov3D_precomp", sc.cov3D_precomp)
+    color, radii, aux = dense_ref.render(sc.W, sc.H, sc.tanfovx, sc.tanfovy, t(sc.bg), t(sc.viewmatrix), t(sc.projmatrix),
+                                         t(sc.campos), means3D, means2D, opac, scale_modifier=scale_modifier, **kw)
+    (color * t(gimg)).sum().backward()
+    return color.detach().numpy(), radii.numpy(), {k: v.grad.numpy() for k, v in leaves.items()}, aux
+
+
+@pytest.mark.parametrize("color_mode,cov_mode,deg,bg", [
+    ("sh", "scale_rot", 3, (0.0, 0.0, 0.0)),
+    ("sh", "scale_rot", 1, (0.3, 0.6, 0.1)),
+    ("precomp", "cov", 3, (1.0, 1.0, 1.0)),
+    ("sh", "cov", 2, (0.0, 0.0, 0.0)),
+    ("precomp", "scale_rot", 0, (0.2, 0.2, 0.2)),
+])
+def test_backward_matches_float64_autograd(oracle, color_mode, cov_mode, deg, bg):
+    n, W, H = 300, 48, 32
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=deg, seed=11, scale_mul=1.5)
+    # push SH so that some colours clamp at 0 and move a few points off-axis past the 1.3*tanfov clamp
+    cloud.shs[:, 0] -= 1.2 * (torch.arange(n) % 7 == 0).float()[:, None]
+    cloud.xyz[::13, 0] *= 2.4
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode)
+    fw = oracle.forward(sc)
+    g = torch.Generator().manual_seed(2)
+    gimg = torch.randn(3, H, W, generator=g).numpy().astype(np.float32)
+    gr = oracle.backward(sc, fw, gimg)
+    color, radii, dg, aux = _dense_grads(sc, cloud, cam, gimg, color_mode, cov_mode, bg)
+    assert np.array_equal(radii, fw["radii"])
+    assert np.abs(color - fw["color"]).max() < 5e-6
+    assert (fw["geom"]["clamped"].sum() > 0) or color_mode != "sh"
+    for name in dg:
+        ref = dg[name]
+        got = gr[name].reshape(ref.shape)
+        err = helpers.rel_to_max(got, ref)
+        assert err < 2e-4, (name, err)
+        assert np.abs(ref).max() > 0, name
+
+
+def test_backward_scale_modifier_semantics(oracle):
+    """dL/dscale is taken w.r.t. mod*scale (the reference kernel drops the factor; SURVEY A8 vi)."""
+    n, W, H = 150, 32, 32
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=0, seed=4, scale_mul=1.2)
+    sc = helpers.oracle_scene(cloud, cam, scale_modifier=0.7)
+    fw = oracle.forward(sc)
+    gimg = np.ones((3, H, W), np.float32)
+    gr = oracle.backward(sc, fw, gimg)
+    _, _, dg, _ = _dense_grads(sc, cloud, cam, gimg, "sh", "scale_rot", (0, 0, 0), scale_modifier=0.7)
+    assert helpers.rel_to_max(gr["scales"], dg["scales"]) < 2e-4
+    assert helpers.rel_to_max(gr["rotations"], dg["rotations"]) < 2e-4
+
+
+def test_culled_gaussians_get_exact_zero_grads(oracle):
+    n, W, H = 200, 32, 32
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=9)
+    cloud.xyz[:40, 2] = -3.5  # behind the camera plane z_view <= 0.2
+    sc = helpers.oracle_scene(cloud, cam)
+    fw = oracle.forward(sc)
+    assert (fw["radii"][:40] == 0).all()
+    gr = oracle.backward(sc, fw, np.ones((3, H, W), np.float32))
+    for k in ("means3D", "means2D", "sh", "opacities", "scales", "rotations", "cov3D_precomp", "colors_precomp"):
+        assert (gr[k][:40] == 0).all(), k
+
+
+def test_config0_plumbing_10k_256_sh0(oracle):
+    """BASELINE.json configs[0]: 10k Gaussians, 256x256, SH degree 0, CPU only."""
+    from scipy.spatial import cKDTree
+
+    def d2(p):
+        pts = p.numpy().astype(np.float64)
+        d, _ = cKDTree(pts).query(pts, k=4)
+        return torch.from_numpy((d[:, 1:] ** 2).mean(1).astype(np.float32))
+    cloud, cam = helpers.cloud_and_camera(10000, 256, 256, sh_degree=0, seed=0, dist2_fn=d2)
+    sc = helpers.oracle_scene(cloud, cam)
+    fw = oracle.forward(sc)
+    assert fw["color"].shape == (3, 256, 256) and np.isfinite(fw["color"]).all()
+    assert (fw["radii"] > 0).sum() > 9000
+    gt = torch.rand(3, 256, 256, generator=torch.Generator().manual_seed(1)).numpy()
+    gimg = (np.sign(fw["color"] - gt) / gt.size).astype(np.float32)  # d l1_loss / d image (utils/loss_utils.py:21-22)
+    gr = oracle.backward(sc, fw, gimg)
+    assert all(np.isfinite(v).all() for v in gr.values() if v is not None)
+    assert np.abs(gr["means2D"][:, :2]).max() > 0
+
+
+def test_dist2_brute_force_vs_kdtree(oracle):
+    from scipy.spatial import cKDTree
+    g = torch.Generator().manual_seed(0)
+    pts = (torch.rand(3000, 3, generator=g) * 2 - 1).numpy().astype(np.float32)
+    got = oracle.dist2(pts)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    want = (d[:, 1:] ** 2).mean(1)
+    assert np.abs(got - want).max() / want.max() < 1e-5
+    # duplicated points: the twin is at distance 0 (self excluded by index only)
+    pts2 = np.concatenate([pts[:10], pts[:10], pts[:10], pts[:10]])
+    assert (oracle.dist2(pts2) == 0).all()
