@@ -1,0 +1,177 @@
+// binning.hip -- tile binning: prefix sum of tiles touched, emission of the
+// (tile, Gaussian) pairs, tile ranges.  Replaces upstream InclusiveSum / duplicateWithKeys /
+// identifyTileRanges.
+//
+// MI355X-first formulation of the reference's "stable sort of (tile << 32 | depth_bits) keys": the
+// Gaussians are first put in (depth, index) order (a stable 32-bit sort over P items), the pairs are
+// then emitted Gaussian-major IN THAT ORDER, and a stable sort on the tile id alone (12-16 bits
+// over D items) yields exactly the list a stable 64-bit sort of the upstream keys yields -- with a
+// third of the bytes per pass and a third of the passes over the D-sized arrays.
+#include "common.h"
+
+#define SC_THREADS 256
+#define SC_PER_THREAD (SCAN_ITEMS / SC_THREADS)
+
+// pass 1: gather tiles_touched into depth-rank order and reduce per block
+__global__ __launch_bounds__(SC_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                                 const uint32_t* __restrict__ tiles,
+                                                                 uint32_t* __restrict__ tt_rank,
+                                                                 uint32_t* __restrict__ bsum, int P) {
+    __shared__ uint32_t ws[4];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * SCAN_ITEMS;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SC_PER_THREAD; k++) {
+        const int r = base + k * SC_THREADS + tid;
+        if (r < P) {
+            const uint32_t t = tiles[sorted_idx[r]];
+            tt_rank[r] = t;
+            sum += t;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((tid & 63) == 0) ws[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// pass 2: exclusive scan of the block sums (one workgroup), total -> count
+__global__ __launch_bounds__(1024) void scan_bsum_kernel(uint32_t* __restrict__ bsum, int nblk,
+                                                         unsigned long long* __restrict__ count) {
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < nblk ? bsum[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wid) woff += wsum[w];
+            total += wsum[w];
+        }
+        const unsigned long long carry = carry_s;
+        if (i < nblk) bsum[i] = (uint32_t)(carry + woff + x - v);
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = carry_s;  // 64-bit total: overflow of the 32-bit index space is detectable
+}
+
+// pass 3: per-block exclusive scan + block base
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ tt_rank,
+                                                                const uint32_t* __restrict__ bsum,
+                                                                uint32_t* __restrict__ offs, int P) {
+    __shared__ uint32_t ws[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int base = blockIdx.x * SCAN_ITEMS + tid * SC_PER_THREAD;  // consecutive items per thread
+    uint32_t v[SC_PER_THREAD];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SC_PER_THREAD; k++) {
+        v[k] = (base + k < P) ? tt_rank[base + k] : 0u;
+        tsum += v[k];
+    }
+    uint32_t x = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) ws[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += ws[w];
+    uint32_t excl = bsum[blockIdx.x] + woff + x - tsum;
+#pragma unroll
+    for (int k = 0; k < SC_PER_THREAD; k++) {
+        if (base + k < P) offs[base + k] = excl;
+        excl += v[k];
+    }
+}
+
+int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
+                      uint32_t* bsum, unsigned long long* count, int P, int debug, hipStream_t s) {
+    const int nblk = (P + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, sorted_idx, tiles, tt_rank, bsum, P);
+    GS_LAUNCH_CHECK("scan.reduce", debug, s);
+    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, count);
+    GS_LAUNCH_CHECK("scan.bsum", debug, s);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, tt_rank, bsum, offs, P);
+    GS_LAUNCH_CHECK("scan.apply", debug, s);
+    return GS_OK;
+}
+
+// Emission of the (tile id, Gaussian index) pairs in depth-rank order, tiles y-outer / x-inner
+// (the upstream duplicateWithKeys order).  Also records each Gaussian's first pair index in its
+// splat record (slot 9): the backward pass addresses its per-pair gradient rows through it.
+__global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                   const uint32_t* __restrict__ tt_rank,
+                                                   const uint32_t* __restrict__ offs, float* __restrict__ rec,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int P,
+                                                   int gx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t tt = tt_rank[r];
+    if (tt == 0) return;
+    const uint32_t idx = sorted_idx[r];
+    uint32_t off = offs[r];
+    float* R = rec + (size_t)idx * REC_F;
+    R[9] = __uint_as_float(off);
+    const uint32_t rmin = __float_as_uint(R[10]), rsz = __float_as_uint(R[11]);
+    const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu, h = rsz >> 16;
+    for (uint32_t y = miny; y < miny + h; y++)
+        for (uint32_t x = minx; x < minx + w; x++) {
+            keys[off] = y * (uint32_t)gx + x;
+            vals[off] = idx;
+            off++;
+        }
+}
+
+int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
+                uint32_t* vals, int P, int gx, int debug, hipStream_t s) {
+    hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, s, sorted_idx, tt_rank, offs, rec, keys, vals,
+                       P, gx);
+    GS_LAUNCH_CHECK("emit", debug, s);
+    return GS_OK;
+}
+
+// ranges[tile] = [first, end) in the sorted list (upstream identifyTileRanges); ranges pre-zeroed.
+__global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ tile_sorted,
+                                                     uint32_t* __restrict__ ranges, int64_t D) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D) return;
+    const uint32_t cur = tile_sorted[j];
+    if (j == 0) {
+        ranges[2 * cur] = 0;
+    } else {
+        const uint32_t prev = tile_sorted[j - 1];
+        if (cur != prev) {
+            ranges[2 * prev + 1] = (uint32_t)j;
+            ranges[2 * cur] = (uint32_t)j;
+        }
+    }
+    if (j == D - 1) ranges[2 * cur + 1] = (uint32_t)D;
+}
+
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
+    if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+    if (D > 0) {
+        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, tile_sorted, ranges, D);
+        GS_LAUNCH_CHECK("ranges", debug, s);
+    }
+    return GS_OK;
+}

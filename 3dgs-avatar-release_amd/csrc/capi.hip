@@ -1,0 +1,250 @@
+// capi.hip -- the extern "C" boundary declared in include/gsplat_mi355.h.  Host-side sequencing of
+// the stages; no device allocation, no implicit synchronisation (except in debug mode).
+#include "common.h"
+#include <string.h>
+
+static thread_local int g_last_hip = 0;
+static thread_local const char* g_last_stage = "";
+void gs_set_error(int hip_err, const char* stage) {
+    g_last_hip = hip_err;
+    g_last_stage = stage;
+}
+
+static int validate(const GsFwdArgs* a) {
+    if (!a) return GS_E_BAD_ARG;
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) return GS_E_BAD_ARG;
+    if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos) return GS_E_BAD_ARG;
+    if (a->P > 0 && (!a->means3D || !a->opacities)) return GS_E_BAD_ARG;
+    if ((a->shs != nullptr) == (a->colors_precomp != nullptr)) return GS_E_EXCLUSIVE;
+    const bool sr = a->scales != nullptr && a->rotations != nullptr;
+    if ((a->scales != nullptr) != (a->rotations != nullptr)) return GS_E_EXCLUSIVE;
+    if (sr == (a->cov3D_precomp != nullptr)) return GS_E_EXCLUSIVE;
+    if (a->shs) {
+        if (a->sh_degree < 0 || a->sh_degree > 3) return GS_E_BAD_ARG;
+        if (a->M < (a->sh_degree + 1) * (a->sh_degree + 1)) return GS_E_BAD_ARG;
+    }
+    if ((a->W + TILE - 1) / TILE > 0xFFFF || (a->H + TILE - 1) / TILE > 0xFFFF) return GS_E_TOO_LARGE;
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_geom_bytes(int32_t P, size_t* out) {
+    if (!out || P < 0) return GS_E_BAD_ARG;
+    *out = geom_layout(P).total;
+    return GS_OK;
+}
+int gs_image_bytes(int32_t W, int32_t H, size_t* out) {
+    if (!out || W <= 0 || H <= 0) return GS_E_BAD_ARG;
+    *out = img_layout(W, H).total;
+    return GS_OK;
+}
+int gs_binning_bytes(int64_t D, int32_t W, int32_t H, size_t* out) {
+    if (!out || D < 0 || W <= 0 || H <= 0) return GS_E_BAD_ARG;
+    if (D > 0xFFFFFFFFll) return GS_E_TOO_LARGE;
+    *out = bin_layout(D).total;
+    return GS_OK;
+}
+int gs_backward_scratch_bytes(int64_t D, size_t* out) {
+    if (!out || D < 0) return GS_E_BAD_ARG;
+    *out = align_up((size_t)(D > 0 ? D : 1) * REC_F * 4, 256);
+    return GS_OK;
+}
+
+int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes,
+                          int32_t* radii, int64_t* count_host_pinned, void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!geom || !img || (a->P > 0 && !radii)) return GS_E_BAD_ARG;
+    const GeomLayout L = geom_layout(a->P);
+    const ImgLayout I = img_layout(a->W, a->H);
+    if (geom_bytes < L.total || img_bytes < I.total) return GS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* g = (char*)geom;
+    unsigned long long* count = (unsigned long long*)(g + L.count);
+    if (a->P == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, 8, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "count.memset"); return GS_E_HIP; }
+    } else {
+        uint32_t* k0 = (uint32_t*)(g + L.key0);
+        uint32_t* k1 = (uint32_t*)(g + L.key1);
+        uint32_t* v0 = (uint32_t*)(g + L.val0);
+        uint32_t* v1 = (uint32_t*)(g + L.val1);
+        rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
+                               (uint32_t*)(g + L.clamped), k0, v0, radii, s);
+        if (rc != GS_OK) return rc;
+        // stable sort by depth bits: ties keep ascending Gaussian index (the reference's tie order)
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, a->debug, s);
+        if (rc != GS_OK) return rc;
+        // 4 passes -> the sorted index ends in (k0, v0)
+        rc = launch_scan_tiles(v0, (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.tt_rank), (uint32_t*)(g + L.offs),
+                               (uint32_t*)(g + L.bsum), count, a->P, a->debug, s);
+        if (rc != GS_OK) return rc;
+    }
+    if (count_host_pinned) {
+        hipError_t e = hipMemcpyAsync(count_host_pinned, count, 8, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "count.copy"); return GS_E_HIP; }
+    }
+    return GS_OK;
+}
+
+int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                      void* img, size_t img_bytes, int64_t D, float* out_color, void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
+    if (D > 0xFFFFFFFFll) return GS_E_TOO_LARGE;
+    const GeomLayout L = geom_layout(a->P);
+    const ImgLayout I = img_layout(a->W, a->H);
+    const BinLayout B = bin_layout(D);
+    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* g = (char*)geom;
+    char* b = (char*)binning;
+    char* im = (char*)img;
+    const int ntiles = I.gx * I.gy;
+    uint32_t* ranges = (uint32_t*)(im + I.ranges);
+    const uint32_t* point_list = nullptr;
+    if (D > 0) {
+        uint32_t* k0 = (uint32_t*)(b + B.key0);
+        uint32_t* k1 = (uint32_t*)(b + B.key1);
+        uint32_t* v0 = (uint32_t*)(b + B.val0);
+        uint32_t* v1 = (uint32_t*)(b + B.val1);
+        rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
+                         (float*)(g + L.rec), k0, v0, a->P, I.gx, a->debug, s);
+        if (rc != GS_OK) return rc;
+        const int bits = tile_bits(ntiles);
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, a->debug, s);
+        if (rc != GS_OK) return rc;
+        const bool odd = radix_passes(bits) & 1;
+        point_list = odd ? v1 : v0;
+        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, a->debug, s);
+        if (rc != GS_OK) return rc;
+    } else {
+        hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+    }
+    rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, a->bg, a->W, a->H, out_color,
+                               (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s);
+    if (rc != GS_OK) return rc;
+    if (a->debug) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { gs_set_error((int)e, "render_forward"); return GS_E_HIP; }
+    }
+    return GS_OK;
+}
+
+int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+                size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
+                const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && (!binning || !scratch))) return GS_E_BAD_ARG;
+    if (a->P > 0 && (!radii || !gr->dL_dmeans3D || !gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dcov3D))
+        return GS_E_BAD_ARG;
+    if (a->P > 0 && a->shs && !gr->dL_dsh) return GS_E_BAD_ARG;
+    if (a->P > 0 && a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return GS_E_BAD_ARG;
+    const GeomLayout L = geom_layout(a->P);
+    const ImgLayout I = img_layout(a->W, a->H);
+    const BinLayout B = bin_layout(D);
+    size_t need = 0;
+    gs_backward_scratch_bytes(D, &need);
+    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && (binning_bytes < B.total || scratch_bytes < need)))
+        return GS_E_WORKSPACE;
+    if (a->P == 0) return GS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const char* g = (const char*)geom;
+    const char* b = (const char*)binning;
+    const char* im = (const char*)img;
+    if (D > 0) {
+        const int bits = tile_bits(I.gx * I.gy);
+        const bool odd = radix_passes(bits) & 1;
+        const uint32_t* point_list = (const uint32_t*)(b + (odd ? B.val1 : B.val0));
+        rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), a->bg, a->W,
+                                    a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix, (float*)scratch, s);
+        if (rc != GS_OK) return rc;
+        if (a->debug) {
+            hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { gs_set_error((int)e, "render_backward"); return GS_E_HIP; }
+        }
+    }
+    return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
+                                    (const uint32_t*)(g + L.clamped), (const float*)scratch, *gr, s);
+}
+
+int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, void* stream) {
+    (void)projmatrix;
+    if (P < 0 || !viewmatrix || (P > 0 && (!means3D || !present))) return GS_E_BAD_ARG;
+    if (P == 0) return GS_OK;
+    return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int knn_workspace_bytes(int32_t P, size_t* out) {
+    if (!out || P < 0) return GS_E_BAD_ARG;
+    *out = knn_ws_bytes(P);
+    return GS_OK;
+}
+int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (P < 0 || (P > 0 && (!points || !mean_d2 || !workspace))) return GS_E_BAD_ARG;
+    if (P == 0) return GS_OK;
+    return launch_knn(P, points, mean_d2, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {
+    if (!geom || !out || P < 0) return GS_E_BAD_ARG;
+    const GeomLayout L = geom_layout(P);
+    char* g = (char*)geom;
+    switch (field) {
+        case 0: *out = g + L.depths; break;
+        case 1: *out = g + L.tiles; break;
+        case 2: *out = g + L.rec; break;
+        case 3: *out = g + L.clamped; break;
+        case 4: *out = g + L.val0; break;
+        case 5: *out = g + L.count; break;
+        default: return GS_E_BAD_ARG;
+    }
+    return GS_OK;
+}
+int gs_binning_field(void* binning, int64_t D, int32_t W, int32_t H, int32_t field, void** out) {
+    if (!binning || !out || D < 0) return GS_E_BAD_ARG;
+    const BinLayout B = bin_layout(D);
+    const ImgLayout I = img_layout(W, H);
+    const bool odd = radix_passes(tile_bits(I.gx * I.gy)) & 1;
+    char* b = (char*)binning;
+    switch (field) {
+        case 0: *out = b + (odd ? B.val1 : B.val0); break;
+        case 1: *out = b + (odd ? B.key1 : B.key0); break;
+        default: return GS_E_BAD_ARG;
+    }
+    return GS_OK;
+}
+int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
+    if (!img || !out) return GS_E_BAD_ARG;
+    const ImgLayout I = img_layout(W, H);
+    char* m = (char*)img;
+    switch (field) {
+        case 0: *out = m + I.ranges; break;
+        case 1: *out = m + I.n_contrib; break;
+        case 2: *out = m + I.final_T; break;
+        default: return GS_E_BAD_ARG;
+    }
+    return GS_OK;
+}
+
+const char* gs_status_string(int code) {
+    switch (code) {
+        case GS_OK: return "ok";
+        case GS_E_BAD_ARG: return "bad argument (null required pointer, non-positive size or unsupported SH degree)";
+        case GS_E_EXCLUSIVE: return "provide exactly one of shs/colors_precomp and exactly one of (scales, rotations)/cov3D_precomp";
+        case GS_E_TOO_LARGE: return "num_rendered or tile grid exceeds the supported index space";
+        case GS_E_HIP: return "HIP error";
+        case GS_E_WORKSPACE: return "state/workspace buffer smaller than gs_*_bytes requires";
+        default: return "unknown status";
+    }
+}
+int gs_last_hip_error(void) { return g_last_hip; }
+const char* gs_last_stage(void) { return g_last_stage; }
+const char* gs_build_info(void) { return "gsplat_mi355 gfx950 wave64 tile16 rec48"; }
+
+}  // extern "C"

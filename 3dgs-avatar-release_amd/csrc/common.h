@@ -1,0 +1,131 @@
+// common.h -- shared declarations of the gfx950 rasterizer library (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsplat_mi355.h"
+
+#define TILE 16                 // tile edge in pixels (parity contract: 16x16)
+#define WAVE 64                 // CDNA wavefront
+#define REC_F 12                // floats per splat record (48 B = 3 x 16 B)
+
+// ---------------------------------------------------------------------------------------------
+// State-buffer layouts.  Pure functions of (P) / (D, W, H) / (W, H): every call re-derives the
+// same carve, so the library keeps no pointers between calls (re-entrant, graph-capturable).
+// ---------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define SORT_ITEMS 4096          // elements per radix-sort block (256 threads x 16)
+#define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
+
+struct GeomLayout {
+    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, tt_rank, offs, bsum, hist, count, total;
+    int nblk_sort, nblk_scan;
+};
+static inline GeomLayout geom_layout(int P) {
+    GeomLayout L;
+    size_t o = 0;
+    size_t n = (size_t)(P > 0 ? P : 1);
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.nblk_sort = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+    L.nblk_scan = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
+    L.rec = take(n * REC_F * 4);
+    L.depths = take(n * 4);
+    L.tiles = take(n * 4);
+    L.clamped = take(n * 4);
+    L.key0 = take(n * 4);
+    L.key1 = take(n * 4);
+    L.val0 = take(n * 4);
+    L.val1 = take(n * 4);
+    L.tt_rank = take(n * 4);
+    L.offs = take(n * 4);
+    L.bsum = take((size_t)(L.nblk_scan + 1) * 4);
+    L.hist = take((size_t)256 * L.nblk_sort * 4);
+    L.count = take(64);
+    L.total = o;
+    return L;
+}
+
+struct BinLayout {
+    size_t key0, key1, val0, val1, hist, total;
+    int nblk_sort;
+};
+static inline BinLayout bin_layout(int64_t D) {
+    BinLayout L;
+    size_t o = 0;
+    size_t n = (size_t)(D > 0 ? D : 1);
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.nblk_sort = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+    L.key0 = take(n * 4);
+    L.key1 = take(n * 4);
+    L.val0 = take(n * 4);
+    L.val1 = take(n * 4);
+    L.hist = take((size_t)256 * L.nblk_sort * 4);
+    L.total = o;
+    return L;
+}
+
+struct ImgLayout {
+    size_t ranges, n_contrib, final_T, total;
+    int gx, gy;
+};
+static inline ImgLayout img_layout(int W, int H) {
+    ImgLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.gx = (W + TILE - 1) / TILE;
+    L.gy = (H + TILE - 1) / TILE;
+    L.ranges = take((size_t)L.gx * L.gy * 8);
+    L.n_contrib = take((size_t)W * H * 4);
+    L.final_T = take((size_t)W * H * 4);
+    L.total = o;
+    return L;
+}
+
+// number of key bits the tile sort must cover, and which of the ping-pong buffers ends up sorted
+static inline int tile_bits(int ntiles) {
+    int b = 1;
+    while ((1 << b) < ntiles) b++;
+    return b;
+}
+static inline int radix_passes(int bits) { return (bits + 7) / 8; }
+
+// ---------------------------------------------------------------------------------------------
+// Error plumbing
+// ---------------------------------------------------------------------------------------------
+void gs_set_error(int hip_err, const char* stage);
+#define GS_LAUNCH_CHECK(stage, dbg, stream)                                            \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ == hipSuccess && (dbg)) e__ = hipStreamSynchronize((hipStream_t)(stream)); \
+        if (e__ != hipSuccess) { gs_set_error((int)e__, stage); return GS_E_HIP; }     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Stage launchers (each enqueues on `s`, returns GS_OK / GS_E_HIP)
+// ---------------------------------------------------------------------------------------------
+int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+
+// stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
+// (k0,v0) and (k1,v1); the result lands in buffer (passes & 1).  `hist` holds 256*nblk u32.
+int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
+                      int debug, hipStream_t s);
+
+int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
+                      uint32_t* bsum, unsigned long long* count, int P, int debug, hipStream_t s);
+int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
+                uint32_t* vals, int P, int gx, int debug, hipStream_t s);
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
+
+int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
+                          int H, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t s);
+int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
+                           int H, const uint32_t* n_contrib, const float* out_color, const float* dL_dpix,
+                           float* entry_grads, hipStream_t s);
+int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
+                             const uint32_t* clamped, const float* entry_grads, const GsGrads& g, hipStream_t s);
+
+int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+size_t knn_ws_bytes(int P);

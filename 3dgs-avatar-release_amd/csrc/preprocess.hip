@@ -1,0 +1,127 @@
+// preprocess.hip -- per-Gaussian forward preprocess and mark_visible (A10).
+// Replaces upstream preprocessCUDA / checkFrustum.  One thread per Gaussian, streaming.
+// Built with -ffp-contract=off: the integer outputs (radii, tile rectangle, tiles_touched, depth
+// key) must be bit-identical to the CPU oracle, so every fp32 operation is individually rounded
+// and evaluated in the order written here.
+#include "common.h"
+#include "gs_math.h"
+
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int deg, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+    float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy,
+    float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
+    uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+
+    float V[16], PV[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { V[k] = viewmatrix[k]; PV[k] = projmatrix[k]; }
+
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    float r2x = 0.f;
+    uint32_t off_bits = 0, rmin_bits = 0, rsize_bits = 0, cl = 0, tt = 0;
+    float depth = 0.f;
+    int radius = 0;
+
+    const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    const float3 pv = xform4x3(p, V);
+    bool ok = pv.z > 0.2f;  // near cull (p_view.z <= 0.2 is culled)
+    if (ok) {
+        const float4 ph = xform4x4(p, PV);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float ppx = ph.x * pw, ppy = ph.y * pw;
+        float c6[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * i + k];
+        } else {
+            const float3 sc = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            cov3d_from_scale_rot(sc, scale_modifier, q, c6);
+        }
+        float cov[3], Mx[2][3], tcl[3], tt2[2];
+        cov2d(p, focal_x, focal_y, tanfovx, tanfovy, c6, V, cov, Mx, tcl, tt2);
+        const float det = cov[0] * cov[2] - cov[1] * cov[1];
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float cA = cov[2] * det_inv, cB = -cov[1] * det_inv, cC = cov[0] * det_inv;
+            const float mid = 0.5f * (cov[0] + cov[2]);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + sq, l2 = mid - sq;
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+            // ndc2Pix in double, as upstream: ((v + 1.0) * S - 1.0) * 0.5
+            const float px = (float)((((double)ppx + 1.0) * (double)W - 1.0) * 0.5);
+            const float py = (float)((((double)ppy + 1.0) * (double)H - 1.0) * 0.5);
+            const int r = (int)my_radius;
+            int minx = (int)((px - r) / TILE), miny = (int)((py - r) / TILE);
+            int maxx = (int)((px + r + TILE - 1) / TILE), maxy = (int)((py + r + TILE - 1) / TILE);
+            minx = min(gx, max(0, minx));
+            miny = min(gy, max(0, miny));
+            maxx = min(gx, max(0, maxx));
+            maxy = min(gy, max(0, maxy));
+            const int w = maxx - minx, h = maxy - miny;
+            if (w * h != 0) {
+                float3 col;
+                if (colors_precomp) {
+                    col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
+                } else {
+                    col = sh_to_rgb(deg, p, make_float3(campos[0], campos[1], campos[2]), shs + (size_t)i * M * 3, &cl);
+                }
+                depth = pv.z;
+                radius = r;
+                tt = (uint32_t)(w * h);
+                r0 = make_float4(px, py, cA, cB);
+                r1 = make_float4(cC, opacities[i], col.x, col.y);
+                r2x = col.z;
+                rmin_bits = (uint32_t)minx | ((uint32_t)miny << 16);
+                rsize_bits = (uint32_t)w | ((uint32_t)h << 16);
+            }
+        }
+    }
+    float4* R = reinterpret_cast<float4*>(rec) + (size_t)i * 3;
+    R[0] = r0;
+    R[1] = r1;
+    R[2] = make_float4(r2x, __uint_as_float(off_bits), __uint_as_float(rmin_bits), __uint_as_float(rsize_bits));
+    depths[i] = depth;
+    tiles[i] = tt;
+    clamped[i] = cl;
+    radii[i] = radius;
+    // depth-sort key: positive float bits are monotone as unsigned; culled Gaussians go last
+    sort_keys[i] = tt ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    sort_vals[i] = (uint32_t)i;
+}
+
+int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, hipStream_t s) {
+    const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
+    const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
+    const int blocks = (a.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.scales,
+                       a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
+                       a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
+                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii);
+    GS_LAUNCH_CHECK("preprocess", a.debug, s);
+    return GS_OK;
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ viewmatrix,
+                                                           uint8_t* __restrict__ present) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float V[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) V[k] = viewmatrix[k];
+    const float3 pv = xform4x3(make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]), V);
+    present[i] = pv.z > 0.2f ? 1 : 0;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    GS_LAUNCH_CHECK("mark_visible", 0, s);
+    return GS_OK;
+}

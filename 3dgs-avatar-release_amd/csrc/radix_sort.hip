@@ -1,0 +1,135 @@
+// radix_sort.hip -- stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
+// Replaces the two cub::DeviceRadixSort::SortPairs calls of the upstream path.
+//
+// Per pass: (1) per-block digit histogram, (2) exclusive scan of the digit-major [256][nblk] table,
+// (3) stable scatter.  Stability inside a block comes from processing the block's 4096 keys in 16
+// rounds of 256 (one key per thread, thread order = key order); inside a round each wave64 ranks
+// equal digits with an 8-step ballot match, and the four waves are chained through LDS counters.
+#include "common.h"
+
+#define RS_THREADS 256
+#define RS_ROUNDS (SORT_ITEMS / RS_THREADS)
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                             uint32_t* __restrict__ hist, int nblk) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+#pragma unroll 4
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t i = base + r * RS_THREADS + tid;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)tid * nblk + blockIdx.x] = h[tid];
+}
+
+// exclusive scan of `m` u32 values in place, one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ data, int64_t m) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 4096) {
+        // 4 consecutive items per thread
+        uint32_t v[4];
+        const int64_t i0 = base + (int64_t)tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < m) ? data[i0 + k] : 0u;
+        uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+        // wave inclusive scan
+        uint32_t x = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wsum[w];
+        uint32_t total = 0;
+        for (int w = 0; w < 16; w++) total += wsum[w];
+        const uint32_t carry = carry_s;
+        uint32_t excl = carry + woff + x - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < m) data[i0 + k] = excl;
+            excl += v[k];
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
+                                                                const uint32_t* __restrict__ vin,
+                                                                uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                int64_t n, int shift, const uint32_t* __restrict__ hist,
+                                                                int nblk) {
+    __shared__ uint32_t gofs[256];     // global base of each digit for this block, advanced per round
+    __shared__ uint32_t wcnt[4][256];  // per-wave digit counts of the current round
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    gofs[tid] = hist[(size_t)tid * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t i = base + r * RS_THREADS + tid;
+        if (base + r * RS_THREADS >= n) break;  // block-uniform
+        const bool valid = i < n;
+        uint32_t key = 0, val = 0;
+        if (valid) { key = kin[i]; val = vin[i]; }
+        const uint32_t digit = (key >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank == 0) wcnt[wid][digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = gofs[digit] + rank;
+            for (int w = 0; w < wid; w++) pos += wcnt[w][digit];
+            kout[pos] = key;
+            vout[pos] = val;
+        }
+        __syncthreads();
+        {
+            const uint32_t add = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+            gofs[tid] += add;
+            wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
+                      int debug, hipStream_t s) {
+    if (n <= 0) return GS_OK;
+    const int nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+    const int passes = radix_passes(bits);
+    uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblk);
+        GS_LAUNCH_CHECK("sort.hist", debug, s);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * nblk);
+        GS_LAUNCH_CHECK("sort.scan", debug, s);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblk);
+        GS_LAUNCH_CHECK("sort.scatter", debug, s);
+        uint32_t* t;
+        t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+    }
+    return GS_OK;
+}

@@ -1,0 +1,224 @@
+"""diff_gaussian_rasterization -- MI355X-native implementation behind the import name the reference
+uses (gaussian_renderer/__init__.py:17: `from diff_gaussian_rasterization import
+GaussianRasterizationSettings, GaussianRasterizer`).
+
+Same public surface as the upstream package of the API generation the reference's call sites pin
+(12-field settings tuple ending in `prefiltered, debug`; `(color, radii)` return;
+gaussian_renderer/__init__.py:85-98,121-129): `GaussianRasterizationSettings`, `GaussianRasterizer`
+(with `markVisible`), `rasterize_gaussians`.  The bodies call the hand-written HIP library through
+the C ABI of include/gsplat_mi355.h; there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import threading
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from gsplat_mi355 import _lib
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+_tls = threading.local()
+
+
+def _pinned_count(device):
+    """A per-thread, per-device pinned int64 the library copies num_rendered into."""
+    cache = getattr(_tls, "pinned", None)
+    if cache is None:
+        cache = _tls.pinned = {}
+    key = device.index
+    if key not in cache:
+        cache[key] = torch.zeros(1, dtype=torch.int64).pin_memory()
+    return cache[key]
+
+
+def _f32c(t, name):
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization: `%s` must be a GPU tensor (this build has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("diff_gaussian_rasterization: `%s` must be float32" % name)
+    return t.contiguous()
+
+
+def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep):
+    a = _lib.GsFwdArgs()
+    P = int(means3D.shape[0])
+    a.P = P
+    a.sh_degree = int(settings.sh_degree)
+    a.M = int(sh.shape[1]) if sh is not None else 0
+    a.W, a.H = int(settings.image_width), int(settings.image_height)
+    dev = means3D.device
+    bg = _f32c(settings.bg.to(dev), "bg")
+    view = _f32c(settings.viewmatrix.to(dev), "viewmatrix")
+    proj = _f32c(settings.projmatrix.to(dev), "projmatrix")
+    campos = _f32c(settings.campos.to(dev), "campos")
+    keep.extend([bg, view, proj, campos])
+    a.bg, a.viewmatrix, a.projmatrix, a.campos = bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+    a.means3D = _lib.ptr(means3D)
+    a.shs = _lib.ptr(sh)
+    a.colors_precomp = _lib.ptr(colors_precomp)
+    a.opacities = _lib.ptr(opacities)
+    a.scales = _lib.ptr(scales)
+    a.rotations = _lib.ptr(rotations)
+    a.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
+    a.scale_modifier = float(settings.scale_modifier)
+    a.tanfovx, a.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
+    a.prefiltered = int(bool(settings.prefiltered))
+    a.debug = int(bool(settings.debug))
+    return a
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        L = _lib.load()
+        means3D = _f32c(means3D, "means3D")
+        if means3D is None:
+            raise RuntimeError("diff_gaussian_rasterization: means3D is empty")
+        sh = _f32c(sh, "shs")
+        colors_precomp = _f32c(colors_precomp, "colors_precomp")
+        opacities = _f32c(opacities, "opacities")
+        scales = _f32c(scales, "scales")
+        rotations = _f32c(rotations, "rotations")
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp")
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        W, H = int(raster_settings.image_width), int(raster_settings.image_height)
+        keep = []
+        with torch.cuda.device(dev):
+            a = _make_args(raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                           keep)
+            stream = torch.cuda.current_stream(dev)
+            sptr = ctypes.c_void_p(stream.cuda_stream)
+            geom_bytes = _lib.nbytes(L.gs_geom_bytes, P)
+            img_bytes = _lib.nbytes(L.gs_image_bytes, W, H)
+            geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
+            img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)
+            count = _pinned_count(dev)
+            _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), geom_bytes, img.data_ptr(), img_bytes,
+                                               radii.data_ptr(), count.data_ptr(), sptr))
+            stream.synchronize()  # the one host sync of the forward: the size of the pair list
+            num_rendered = int(count.item())
+            bin_bytes = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
+            binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
+                                           img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr))
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(means3D, sh if sh is not None else empty,
+                              colors_precomp if colors_precomp is not None else empty, opacities,
+                              scales if scales is not None else empty, rotations if rotations is not None else empty,
+                              cov3Ds_precomp if cov3Ds_precomp is not None else empty, radii, geom, binning, img, color)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        L = _lib.load()
+        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
+         color) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.present
+        settings = ctx.raster_settings
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        W, H = int(settings.image_width), int(settings.image_height)
+        D = ctx.num_rendered
+        g = _f32c(grad_out_color, "grad_out_color")
+        keep = []
+        with torch.cuda.device(dev):
+            a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
+                           scales if has_sr else None, rotations if has_sr else None,
+                           cov3Ds_precomp if has_cov else None, keep)
+            sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            scratch_bytes = _lib.nbytes(L.gs_backward_scratch_bytes, D)
+            scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            M = int(sh.shape[1]) if has_sh else 0
+            f = dict(dtype=torch.float32, device=dev)
+            d_means3D = torch.empty(P, 3, **f)
+            d_means2D = torch.empty(P, 3, **f)
+            d_colors = torch.empty(P, 3, **f)
+            d_opacity = torch.empty(P, 1, **f)
+            d_cov3D = torch.empty(P, 6, **f)
+            d_sh = torch.empty(P, M, 3, **f) if has_sh else None
+            d_scales = torch.empty(P, 3, **f) if has_sr else None
+            d_rot = torch.empty(P, 4, **f) if has_sr else None
+            gr = _lib.GsGrads(_lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_sh), _lib.ptr(d_colors),
+                              _lib.ptr(d_opacity), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov3D))
+            _lib.check(L.gs_backward(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
+                                     binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
+                                     color.data_ptr(), g.data_ptr(), scratch.data_ptr(), scratch_bytes,
+                                     ctypes.byref(gr), sptr))
+        return (d_means3D, d_means2D, d_sh, d_colors if has_col else None, d_opacity, d_scales, d_rot,
+                d_cov3D if has_cov else None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: z_view > 0.2 (upstream mark_visible / checkFrustum)."""
+        L = _lib.load()
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions, "positions")
+            P = int(pos.shape[0])
+            out = torch.zeros(P, dtype=torch.uint8, device=pos.device)
+            view = _f32c(rs.viewmatrix.to(pos.device), "viewmatrix")
+            proj = _f32c(rs.projmatrix.to(pos.device), "projmatrix")
+            with torch.cuda.device(pos.device):
+                sptr = ctypes.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+                _lib.check(L.gs_mark_visible(P, pos.data_ptr(), view.data_ptr(), proj.data_ptr(), _lib.ptr(out), sptr))
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings)

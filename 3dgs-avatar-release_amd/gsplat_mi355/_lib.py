@@ -1,0 +1,95 @@
+"""ctypes binding of libgsplat_mi355.so (include/gsplat_mi355.h).  There is NO fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsplat_mi355.so")
+
+
+class GsFwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", c_int32), ("sh_degree", c_int32), ("M", c_int32), ("W", c_int32), ("H", c_int32),
+        ("bg", c_void_p), ("means3D", c_void_p), ("shs", c_void_p), ("colors_precomp", c_void_p),
+        ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p),
+        ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("campos", c_void_p),
+        ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
+        ("prefiltered", c_int32), ("debug", c_int32),
+    ]
+
+
+class GsGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dsh", "dL_dcolors", "dL_dopacity",
+                                        "dL_dscales", "dL_drotations", "dL_dcov3D")]
+
+
+EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_scratch_bytes",
+           "gs_forward_preprocess", "gs_forward_render", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
+           "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
+           "gs_last_hip_error", "gs_last_stage", "gs_build_info"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Loads the HIP library (torch first, so that its bundled HIP runtime is the one both share)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (libamdhip64 must come from torch's process image)
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgsplat_mi355.so not found at %s: build it with "
+                               "`python 3dgs-avatar-release_amd/build.py` (there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.gs_geom_bytes.argtypes = [c_int32, POINTER(c_size_t)]
+        L.gs_image_bytes.argtypes = [c_int32, c_int32, POINTER(c_size_t)]
+        L.gs_binning_bytes.argtypes = [c_int64, c_int32, c_int32, POINTER(c_size_t)]
+        L.gs_backward_scratch_bytes.argtypes = [c_int64, POINTER(c_size_t)]
+        L.gs_forward_preprocess.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                                            c_void_p, c_void_p]
+        L.gs_forward_render.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
+                                        c_int64, c_void_p, c_void_p]
+        L.gs_backward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                                  c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(GsGrads), c_void_p]
+        L.gs_mark_visible.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.knn_workspace_bytes.argtypes = [c_int32, POINTER(c_size_t)]
+        L.knn_dist2.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.gs_geom_field.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
+        L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        for name in EXPORTS:
+            getattr(L, name).restype = c_int
+        L.gs_status_string.restype = c_char_p
+        L.gs_status_string.argtypes = [c_int]
+        L.gs_last_stage.restype = c_char_p
+        L.gs_build_info.restype = c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = load()
+        msg = L.gs_status_string(rc).decode()
+        if rc == -4:
+            msg += " %d in stage '%s'" % (L.gs_last_hip_error(), L.gs_last_stage().decode())
+        raise RuntimeError("gsplat_mi355: " + msg)
+
+
+def nbytes(fn, *args):
+    out = c_size_t(0)
+    check(fn(*args, ctypes.byref(out)))
+    return int(out.value)
+
+
+def ptr(t):
+    """Device pointer of a tensor, or None (NULL = absent) for None / empty tensors."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()

@@ -1,0 +1,73 @@
+"""Parity-test introspection: runs the two forward phases through the C ABI and copies every
+intermediate of the opaque state buffers back as numpy arrays (gs_*_field of include/gsplat_mi355.h)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from gsplat_mi355 import _lib
+from diff_gaussian_rasterization import GaussianRasterizationSettings, _make_args, _f32c
+
+
+def _view(owner, ptr, nbytes, dtype):
+    """numpy copy of `nbytes` at device address `ptr`, which lies inside the uint8 tensor `owner`."""
+    off = ptr - owner.data_ptr()
+    assert 0 <= off and off + nbytes <= owner.numel()
+    return owner[off:off + nbytes].cpu().numpy().view(dtype).copy()
+
+
+def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                  cov3D_precomp=None):
+    """Runs preprocess + render through the C ABI; returns dict(color, radii, geom=..., binning=..., image=...)."""
+    L = _lib.load()
+    dev = means3D.device
+    means3D = _f32c(means3D, "means3D")
+    shs, colors_precomp = _f32c(shs, "shs"), _f32c(colors_precomp, "colors_precomp")
+    opacities = _f32c(opacities, "opacities")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov")
+    P = int(means3D.shape[0])
+    W, H = int(settings.image_width), int(settings.image_height)
+    keep = []
+    with torch.cuda.device(dev):
+        a = _make_args(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, keep)
+        stream = torch.cuda.current_stream(dev)
+        sptr = ctypes.c_void_p(stream.cuda_stream)
+        gb = _lib.nbytes(L.gs_geom_bytes, P)
+        ib = _lib.nbytes(L.gs_image_bytes, W, H)
+        geom = torch.zeros(gb, dtype=torch.uint8, device=dev)
+        img = torch.zeros(ib, dtype=torch.uint8, device=dev)
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int64).pin_memory()
+        _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), gb, img.data_ptr(), ib, radii.data_ptr(),
+                                           count.data_ptr(), sptr))
+        stream.synchronize()
+        D = int(count.item())
+        bb = _lib.nbytes(L.gs_binning_bytes, D, W, H)
+        binning = torch.zeros(bb, dtype=torch.uint8, device=dev)
+        color = torch.zeros(3, H, W, device=dev)
+        _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), gb, binning.data_ptr(), bb, img.data_ptr(), ib,
+                                       D, color.data_ptr(), sptr))
+        stream.synchronize()
+
+        def field(fn, *args):
+            out = ctypes.c_void_p(0)
+            _lib.check(fn(*args, ctypes.byref(out)))
+            return out.value
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        g = dict(
+            depths=_view(geom, field(L.gs_geom_field, geom.data_ptr(), P, 0), 4 * P, np.float32),
+            tiles_touched=_view(geom, field(L.gs_geom_field, geom.data_ptr(), P, 1), 4 * P, np.uint32),
+            rec=_view(geom, field(L.gs_geom_field, geom.data_ptr(), P, 2), 48 * P, np.float32).reshape(P, 12),
+            clamped=_view(geom, field(L.gs_geom_field, geom.data_ptr(), P, 3), 4 * P, np.uint32),
+            sorted_idx=_view(geom, field(L.gs_geom_field, geom.data_ptr(), P, 4), 4 * P, np.uint32),
+        ) if P > 0 else {}
+        b = dict(
+            point_list=_view(binning, field(L.gs_binning_field, binning.data_ptr(), D, W, H, 0), 4 * D, np.uint32),
+            tile_ids=_view(binning, field(L.gs_binning_field, binning.data_ptr(), D, W, H, 1), 4 * D, np.uint32),
+        ) if D > 0 else dict(point_list=np.zeros(0, np.uint32), tile_ids=np.zeros(0, np.uint32))
+        im = dict(
+            ranges=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 0), 8 * gx * gy, np.uint32).reshape(-1, 2),
+            n_contrib=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 1), 4 * W * H, np.uint32).reshape(H, W),
+            final_T=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 2), 4 * W * H, np.float32).reshape(H, W),
+        )
+    return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im)

@@ -1,0 +1,114 @@
+"""`render()`-shaped harness: reproduces, in order, the call sequence of the reference's
+gaussian_renderer/__init__.py:59-153 on top of the drop-in `diff_gaussian_rasterization` package, and
+the part of the train step that touches the rasterizer (train.py:114-124,143-153,179,217-220).
+The deformer / texture modules upstream of the seam are out of scope: the Gaussian
+state arrives post-activation as a `GaussianCloud`.
+"""
+import math
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+class Pipe(object):
+    """pipeline.* keys the renderer reads (configs/config.yaml:89-92)."""
+
+    def __init__(self, compute_cov3D_python=False, convert_SHs_python=False, debug=False):
+        self.compute_cov3D_python = compute_cov3D_python
+        self.convert_SHs_python = convert_SHs_python
+        self.debug = debug
+
+
+class RenderPackage(object):
+    """Result holder with the fields of gaussian_renderer/__init__.py:20-55,146-153."""
+
+    def __init__(self, **data):
+        self.data = data
+
+    def __getitem__(self, item):
+        return self.data[item]
+
+    def __getattr__(self, item):
+        try:
+            return self.__dict__["data"][item]
+        except KeyError:
+            raise AttributeError(item)
+
+
+def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, return_opacity=False):
+    """data: camera (FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
+    camera_center); pc: tensors named as GaussianModel's getters (xyz, opacity, scales, rotations, shs).
+    If `colors_precomp` is given it is used (the reference always does: gaussian_renderer/__init__.py:117-124);
+    otherwise SHs are handed to the rasterizer for in-kernel SH->RGB (north_star)."""
+    xyz = pc.xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(data.FoVx * 0.5)
+    tanfovy = math.tan(data.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(data.image_height), image_width=int(data.image_width), tanfovx=tanfovx, tanfovy=tanfovy,
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=data.world_view_transform,
+        projmatrix=data.full_proj_transform, sh_degree=pc.sh_degree, campos=data.camera_center, prefiltered=False,
+        debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = pc.opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.covariance6(scaling_modifier)
+    else:
+        scales, rotations = pc.scales, pc.rotations
+    shs = None if colors_precomp is not None else pc.shs
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                       opacities=opacity, scales=scales, rotations=rotations,
+                                       cov3D_precomp=cov3D_precomp)
+    opacity_image = None
+    if return_opacity:
+        opacity_image, _ = rasterizer(means3D=means3D, means2D=means2D, shs=None,
+                                      colors_precomp=torch.ones(opacity.shape[0], 3, device=opacity.device),
+                                      opacities=opacity, scales=scales, rotations=rotations,
+                                      cov3D_precomp=cov3D_precomp)
+        opacity_image = opacity_image[:1]
+    return RenderPackage(deformed_gaussian=pc, render=rendered_image, viewspace_points=screenspace_points,
+                         visibility_filter=radii > 0, radii=radii, opacity_render=opacity_image)
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()  # utils/loss_utils.py:21-22
+
+
+class DensifyStats(object):
+    """max_radii2D / xyz_gradient_accum / denom bookkeeping of train.py:217-220 and
+    scene/gaussian_model.py:464-466."""
+
+    def __init__(self, n, device):
+        self.max_radii2D = torch.zeros(n, device=device)
+        self.xyz_gradient_accum = torch.zeros(n, 1, device=device)
+        self.denom = torch.zeros(n, 1, device=device)
+
+    def update(self, pkg):
+        vf, radii = pkg.visibility_filter, pkg.radii
+        self.max_radii2D[vf] = torch.max(self.max_radii2D[vf], radii[vf].float())
+        self.xyz_gradient_accum[vf] += torch.norm(pkg.viewspace_points.grad[vf, :2], dim=-1, keepdim=True)
+        self.denom[vf] += 1
+
+
+def train_step(data, pc, pipe, bg_color, gt_image, gt_mask=None, lambda_mask=0.0, stats=None):
+    """One forward+backward of the rasterizer part of the reference's train step: L1 image loss
+    (train.py:121), optional L1 mask loss on the opacity render (train.py:143-153), .backward()
+    (train.py:179), densification statistics (train.py:219-220)."""
+    use_mask = lambda_mask > 0.0 and gt_mask is not None
+    pkg = render(data, pc, pipe, bg_color, return_opacity=use_mask)
+    loss = l1_loss(pkg.render, gt_image)
+    if use_mask:
+        loss = loss + lambda_mask * l1_loss(pkg.opacity_render, gt_mask)
+    loss.backward()
+    if stats is not None:
+        with torch.no_grad():
+            stats.update(pkg)
+    return loss, pkg

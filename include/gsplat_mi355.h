@@ -1,0 +1,139 @@
+/*
+ * gsplat_mi355.h -- C ABI of libgsplat_mi355.so: the MI355X (gfx950) differentiable
+ * Gaussian-splat rasterizer and the distCUDA2 K-NN initialiser.
+ *
+ * Drop-in boundary.  The reference reaches this path through two Python imports of
+ * third-party torch C++ extensions whose source is NOT vendored in the reference tree:
+ *   - `from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`
+ *     (gaussian_renderer/__init__.py:17; settings built at :85-98, module at :100, calls at
+ *     :121-129 and :133-141)  ->  upstream `_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`,
+ *     `_C.mark_visible`
+ *   - `from simple_knn._C import distCUDA2` (scene/gaussian_model.py:20, call at :186)
+ * Each entry point below names the upstream binding it replaces.  Plain pointers and sizes only:
+ * no torch types.  Every pointer is a DEVICE pointer unless it says "host".  The library never
+ * allocates or frees device memory and never synchronises the stream except where stated; all
+ * work is enqueued on the caller's `stream` (a hipStream_t passed as void*), so calls are
+ * re-entrant across streams and devices (the caller selects the device).
+ *
+ * All entry points return 0 on success, a negative GS_E_* code on failure; `gs_status_string`
+ * turns a code into text.  A NULL optional pointer means "absent", mirroring the upstream
+ * wrapper's empty-tensor convention (gaussian_renderer/__init__.py:107-129).
+ */
+#ifndef GSPLAT_MI355_H
+#define GSPLAT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_E_BAD_ARG (-1)      /* NULL required pointer, non-positive size, bad sh degree   */
+#define GS_E_EXCLUSIVE (-2)    /* both / neither of (shs | colors_precomp) or (scales+rotations | cov3D_precomp) */
+#define GS_E_TOO_LARGE (-3)    /* num_rendered or tile count exceeds the 32-bit index space  */
+#define GS_E_HIP (-4)          /* a HIP launch or API call failed (see gs_last_hip_error)    */
+#define GS_E_WORKSPACE (-5)    /* a caller-provided buffer is smaller than gs_*_bytes says    */
+
+/* Arguments of one rasterizer call: the fields of GaussianRasterizationSettings
+ * (gaussian_renderer/__init__.py:85-98) plus the tensors of GaussianRasterizer.forward
+ * (:121-129), flattened.  Shapes (fp32, contiguous): means3D[P,3], opacities[P], shs[P,M,3]
+ * (coefficient-major, channel-minor; scene/gaussian_model.py:145-148), colors_precomp[P,3],
+ * scales[P,3], rotations[P,4] (w,x,y,z; utils/general_utils.py:94-97), cov3D_precomp[P,6]
+ * ([xx,xy,xz,yy,yz,zz]; utils/general_utils.py:73-85), viewmatrix[16] and projmatrix[16]
+ * (row-vector convention, scene/cameras.py:35-39), campos[3], bg[3]. */
+typedef struct GsFwdArgs {
+    int32_t P;          /* number of Gaussians                                  */
+    int32_t sh_degree;  /* active SH degree 0..3 (settings.sh_degree)           */
+    int32_t M;          /* SH coefficients present per channel: shs.shape[1]    */
+    int32_t W, H;       /* image_width, image_height                            */
+    const float* bg;
+    const float* means3D;
+    const float* shs;            /* NULL if colors_precomp given */
+    const float* colors_precomp; /* NULL if shs given            */
+    const float* opacities;
+    const float* scales;         /* NULL if cov3D_precomp given  */
+    const float* rotations;      /* NULL if cov3D_precomp given  */
+    const float* cov3D_precomp;  /* NULL if scales/rotations     */
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    float scale_modifier, tanfovx, tanfovy;
+    int32_t prefiltered; /* accepted for API parity; culled points are skipped either way */
+    int32_t debug;       /* !=0: synchronise + check after every kernel, name the failing stage */
+} GsFwdArgs;
+
+/* The eight gradient outputs of upstream `rasterize_gaussians_backward`, in the order the
+ * autograd wrapper returns them.  Every non-NULL array is written IN FULL by the call (zeros for
+ * culled Gaussians): the caller does not need to pre-zero.  dL_dsh may be NULL when shs is absent,
+ * dL_dscales / dL_drotations when cov3D_precomp was given. */
+typedef struct GsGrads {
+    float* dL_dmeans3D;  /* [P,3] */
+    float* dL_dmeans2D;  /* [P,3]  x,y = d/d(NDC centre), z = 0 (consumed as .grad[:, :2], scene/gaussian_model.py:464-466) */
+    float* dL_dsh;       /* [P,M,3] */
+    float* dL_dcolors;   /* [P,3]  gradient of colors_precomp (or of the SH colour before the clamp mask) */
+    float* dL_dopacity;  /* [P,1] */
+    float* dL_dscales;   /* [P,3] */
+    float* dL_drotations;/* [P,4] */
+    float* dL_dcov3D;    /* [P,6] */
+} GsGrads;
+
+/* ---- state-buffer sizes (the caller owns every allocation; upstream grew torch byte tensors
+ * through a resize callback: geomBuffer / binningBuffer / imgBuffer) ---- */
+int gs_geom_bytes(int32_t P, size_t* out);
+int gs_image_bytes(int32_t W, int32_t H, size_t* out);
+int gs_binning_bytes(int64_t num_rendered, int32_t W, int32_t H, size_t* out);
+int gs_backward_scratch_bytes(int64_t num_rendered, size_t* out);
+
+/* ---- forward, phase 1 (replaces the first half of upstream rasterize_gaussians: preprocess +
+ * prefix sum).  Runs: per-Gaussian preprocess (cull, EWA projection, conic, radius, tile rect,
+ * SH->RGB), a stable depth sort of the Gaussians, and the prefix sum of tiles touched.
+ * Writes radii[P] (int32).  The number of (tile, Gaussian) pairs `num_rendered` is left in the geom
+ * state and, if `count_host_pinned` is non-NULL, copied asynchronously (same stream) into that
+ * HOST-pinned int64; the caller synchronises before reading it.  No implicit synchronisation. */
+int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes,
+                          int32_t* radii, int64_t* count_host_pinned, void* stream);
+
+/* ---- forward, phase 2 (second half of upstream rasterize_gaussians: duplicateWithKeys, sort,
+ * identifyTileRanges, render).  `num_rendered` must be the value phase 1 produced.  Writes
+ * out_color[3,H,W]. */
+int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                      void* img, size_t img_bytes, int64_t num_rendered, float* out_color, void* stream);
+
+/* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
+ * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `scratch` holds
+ * gs_backward_scratch_bytes(num_rendered) bytes. */
+int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+                size_t binning_bytes, const void* img, size_t img_bytes, int64_t num_rendered,
+                const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,
+                const GsGrads* grads, void* stream);
+
+/* ---- upstream mark_visible / GaussianRasterizer.markVisible: present[i] = (z_view > 0.2) ---- */
+int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, void* stream);
+
+/* ---- simple_knn._C.distCUDA2 (scene/gaussian_model.py:186): mean squared distance to the three
+ * nearest other points.  points[P,3] fp32 -> mean_d2[P] fp32. ---- */
+int knn_workspace_bytes(int32_t P, size_t* out);
+int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
+ *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
+ *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))
+ *           3 clamped bitmask u32[P]   4 depth-sorted Gaussian index u32[P]   5 num_rendered u64[1]
+ *  binning: 0 point_list u32[D] (sorted (tile, depth) order)   1 sorted tile ids u32[D]
+ *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W] */
+int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
+int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
+int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
+
+const char* gs_status_string(int code);
+int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */
+const char* gs_last_stage(void); /* name of the stage that failed (debug mode names every kernel) */
+const char* gs_build_info(void); /* "gfx950 ..." */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_MI355_H */

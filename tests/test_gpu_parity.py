@@ -1,0 +1,279 @@
+"""GPU parity: the HIP path (through the C ABI / the drop-in Python packages) against the CPU oracle on
+the same seeded inputs.  Bar (BASELINE.json north_star): integer / index outputs bit-exact;
+image and gradients within 1e-5 relative to the per-tensor maximum, fp32.
+
+A note on the float bar: alpha is compared against 1/255 and T against 1e-4 per (pixel, Gaussian)
+pair; the device's v_exp_f32 and glibc's expf differ in the last bits, so out of ~1e6-1e9 pairs a few
+land on opposite sides of a threshold (the real CUDA kernel has the same property against any CPU
+restatement).  Such a flip moves one pixel by up to T*alpha*|c| ~ 4e-3.  The float assertions below
+therefore bound BOTH the bulk error (<= 1e-5 of the tensor maximum for all but a 2e-5 fraction of
+elements) and the outliers (<= 1e-2 absolute for the image)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _settings(cam, cloud, bg, dev, scale_modifier=1.0, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.tensor(bg, dtype=torch.float32, device=dev),
+        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
+        projmatrix=cam.full_proj_transform.to(dev), sh_degree=cloud.sh_degree, campos=cam.camera_center.to(dev),
+        prefiltered=False, debug=debug)
+
+
+def _inputs(cloud, cam, color_mode, cov_mode, dev, scale_modifier=1.0):
+    kw = {}
+    if color_mode == "sh":
+        kw["shs"] = cloud.shs.to(dev)
+    else:
+        kw["colors_precomp"] = helpers.precomp_colors(cloud, cam).to(dev)
+    if cov_mode == "scale_rot":
+        kw["scales"] = cloud.scales.to(dev)
+        kw["rotations"] = cloud.rotations.to(dev)
+    else:
+        kw["cov3D_precomp"] = cloud.covariance6(scale_modifier).to(dev)
+    return kw
+
+
+def _bulk_close(got, want, tol=TOL, frac=2e-5, name=""):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    m = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want) / m
+    bad = (err > tol).mean()
+    assert bad <= frac, "%s: %.3g of elements beyond %g (max rel err %.3g)" % (name, bad, tol, err.max())
+    return err.max()
+
+
+COMBOS = [("sh", "scale_rot", 3), ("precomp", "cov", 3), ("sh", "cov", 1), ("precomp", "scale_rot", 0), ("sh", "scale_rot", 2)]
+
+
+@pytest.mark.parametrize("color_mode,cov_mode,deg", COMBOS)
+def test_preprocess_and_binning_bit_exact(oracle, color_mode, cov_mode, deg):
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n, W, H = 3000, 200, 136  # ragged: not a multiple of 16
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=deg, seed=21, scale_mul=1.3)
+    cloud.xyz[:50, 2] = -3.5   # behind the near plane
+    cloud.xyz[50:80, 0] *= 3.0  # beyond the 1.3*tanfov clamp
+    cloud.shs[:, 0] -= 1.2 * (torch.arange(n) % 5 == 0).float()[:, None]
+    bg = (0.1, 0.3, 0.2)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode)
+    fw = oracle.forward(sc)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             **_inputs(cloud, cam, color_mode, cov_mode, dev))
+    og, ob, oi = fw["geom"], fw["binning"], fw["image"]
+    # --- integers: bit-exact
+    assert np.array_equal(st["radii"], og["radii"])
+    assert np.array_equal(st["geom"]["tiles_touched"], og["tiles_touched"])
+    assert st["D"] == ob["D"]
+    vis = og["radii"] > 0
+    rec = st["geom"]["rec"]
+    rmin = rec[:, 10].view(np.uint32)
+    rsz = rec[:, 11].view(np.uint32)
+    assert np.array_equal((rmin & 0xFFFF)[vis], og["rect"][vis, 0]) and np.array_equal((rmin >> 16)[vis], og["rect"][vis, 1])
+    assert np.array_equal((rsz & 0xFFFF)[vis], (og["rect"][:, 2] - og["rect"][:, 0])[vis])
+    assert np.array_equal((rsz >> 16)[vis], (og["rect"][:, 3] - og["rect"][:, 1])[vis])
+    assert np.array_equal(st["geom"]["depths"].view(np.uint32), og["depths"].view(np.uint32))  # the sort key
+    # --- per-Gaussian floats feeding the integers: also bit-exact (no-contraction build)
+    assert np.array_equal(rec[vis, 0:2].view(np.uint32), og["xy"][vis].view(np.uint32))
+    assert np.array_equal(rec[vis, 2:5].view(np.uint32), og["conic_opacity"][vis, :3].view(np.uint32))
+    assert np.array_equal(rec[vis, 5], og["conic_opacity"][vis, 3])
+    assert np.abs(rec[vis, 6:9] - og["rgb"][vis]).max() <= 1e-6
+    if color_mode == "sh":
+        cl = st["geom"]["clamped"]
+        bits = np.stack([(cl >> c) & 1 for c in range(3)], 1)
+        assert np.array_equal(bits[vis], og["clamped"][vis])
+    # --- the sorted (tile, depth) list and the tile ranges: bit-exact
+    assert np.array_equal(st["binning"]["point_list"], ob["point_list"])
+    assert np.array_equal(st["binning"]["tile_ids"], (ob["keys"] >> np.uint64(32)).astype(np.uint32))
+    nz = ob["ranges"][:, 1] > ob["ranges"][:, 0]
+    assert np.array_equal(st["image"]["ranges"][nz], ob["ranges"][nz])
+    assert (st["image"]["ranges"][~nz, 1] == st["image"]["ranges"][~nz, 0]).all()
+    # --- image
+    _bulk_close(st["color"], fw["color"], name="color")
+    assert np.abs(st["color"] - fw["color"]).max() < 1e-2
+    _bulk_close(st["image"]["final_T"], oi["final_T"], name="final_T")
+    assert (st["image"]["n_contrib"] != oi["n_contrib"]).mean() < 1e-4
+
+
+@pytest.mark.parametrize("color_mode,cov_mode,deg", COMBOS)
+def test_backward_matches_oracle(oracle, color_mode, cov_mode, deg):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 4000, 160, 120
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=deg, seed=31, scale_mul=1.3)
+    cloud.xyz[:50, 2] = -3.5
+    cloud.xyz[50:80, 0] *= 3.0
+    cloud.shs[:, 0] -= 1.2 * (torch.arange(n) % 5 == 0).float()[:, None]
+    bg = (0.25, 0.5, 0.75)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode)
+    fw = oracle.forward(sc)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
+    want = oracle.backward(sc, fw, gimg.numpy())
+
+    kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, color_mode, cov_mode, dev).items()}
+    means3D = cloud.xyz.to(dev).requires_grad_(True)
+    means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+    opac = cloud.opacity.to(dev).requires_grad_(True)
+    rast = GaussianRasterizer(_settings(cam, cloud, bg, dev))
+    color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+    (color * gimg.to(dev)).sum().backward()
+    assert np.array_equal(radii.cpu().numpy(), fw["radii"])
+    _bulk_close(color.detach().cpu().numpy(), fw["color"], name="color")
+    got = dict(means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad)
+    names = dict(shs="sh", colors_precomp="colors_precomp", scales="scales", rotations="rotations",
+                 cov3D_precomp="cov3D_precomp")
+    for k, v in kw.items():
+        got[names[k]] = v.grad
+    for name, gt in got.items():
+        assert gt is not None, name
+        w = want[name].reshape(gt.shape)
+        # gradients sum ~1e3 float terms per Gaussian in a different order than the oracle: allow 2e-5 bulk
+        _bulk_close(gt.cpu().numpy(), w, tol=2e-5, frac=1e-4, name=name)
+        assert np.abs(w).max() > 0
+    culled = fw["radii"] == 0
+    for name, gt in got.items():
+        assert (gt.cpu().numpy()[culled] == 0).all(), name
+
+
+def test_empty_and_degenerate_inputs(oracle):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cloud, cam = helpers.cloud_and_camera(64, 48, 48, sh_degree=0, seed=1)
+    cloud.xyz[:, 2] = -10.0  # everything culled: D == 0
+    bg = (0.3, 0.2, 0.1)
+    rast = GaussianRasterizer(_settings(cam, cloud, bg, dev))
+    means3D = cloud.xyz.to(dev).requires_grad_(True)
+    means2D = torch.zeros(64, 3, device=dev, requires_grad=True)
+    color, radii = rast(means3D=means3D, means2D=means2D, opacities=cloud.opacity.to(dev), shs=cloud.shs.to(dev),
+                        scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    assert (radii == 0).all()
+    assert torch.allclose(color, torch.tensor(bg, device=dev)[:, None, None].expand_as(color))
+    color.sum().backward()
+    assert (means3D.grad == 0).all() and (means2D.grad == 0).all()
+
+
+def test_argument_validation_matches_upstream_messages():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cloud, cam = helpers.cloud_and_camera(16, 32, 32, sh_degree=0, seed=1)
+    rast = GaussianRasterizer(_settings(cam, cloud, (0, 0, 0), dev))
+    x, o = cloud.xyz.to(dev), cloud.opacity.to(dev)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=x, means2D=x, opacities=o, scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=x, means2D=x, opacities=o, shs=cloud.shs.to(dev))
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        rast(means3D=x.cpu(), means2D=x, opacities=o, shs=cloud.shs.to(dev), scales=cloud.scales.to(dev),
+             rotations=cloud.rotations.to(dev))
+
+
+def test_mark_visible(oracle):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cloud, cam = helpers.cloud_and_camera(5000, 64, 64, sh_degree=0, seed=2)
+    cloud.xyz[:, 2] = torch.linspace(-4.0, 1.0, 5000)
+    rast = GaussianRasterizer(_settings(cam, cloud, (0, 0, 0), dev))
+    got = rast.markVisible(cloud.xyz.to(dev)).cpu().numpy()
+    want = oracle.mark_visible(cloud.xyz.numpy(), cam.world_view_transform.numpy())
+    assert got.dtype == np.bool_ and np.array_equal(got, want) and 0 < want.sum() < 5000
+
+
+def test_distCUDA2_exact_vs_brute_force(oracle):
+    from simple_knn._C import distCUDA2
+    dev = torch.device("cuda:0")
+    for n, seed in [(4096, 0), (5000, 1), (777, 2), (4, 3)]:
+        pts = torch.rand(n, 3, generator=torch.Generator().manual_seed(seed)) * 2 - 1
+        if n == 5000:
+            pts[:, 2] *= 1e-3  # nearly planar: degenerate Morton axis
+        got = distCUDA2(pts.to(dev)).cpu().numpy()
+        want = oracle.dist2(pts.numpy())
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+    # duplicates: distance 0, the caller clamps to 1e-7 (scene/gaussian_model.py:186)
+    pts = torch.rand(100, 3).repeat(4, 1)
+    got = distCUDA2(pts.to(dev))
+    assert (got == 0).all()
+    assert (torch.clamp_min(got, 0.0000001) == 1e-7).all()
+
+
+def test_render_harness_train_step_config_shapes(oracle):
+    """The render()-shaped harness on the reference's default input combination
+    (colors_precomp + cov3D_precomp, two rasterizer calls per step) against the oracle."""
+    from gsplat_mi355.render import DensifyStats, Pipe, train_step
+    dev = torch.device("cuda:0")
+    n, W, H = 3000, 128, 128
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=8, scale_mul=1.2)
+    pc = cloud.to(dev)
+    for f in ("xyz", "scales", "rotations", "opacity", "shs"):
+        getattr(pc, f).requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(2)) > 0.5).float().to(dev)
+    stats = DensifyStats(n, dev)
+    bg = torch.zeros(3, device=dev)
+    loss, pkg = train_step(cam.to(dev), pc, Pipe(compute_cov3D_python=True), bg, gt, gt_mask=mask, lambda_mask=0.1,
+                           stats=stats)
+    # oracle: same two renders
+    cam.to("cpu")
+    sc = helpers.oracle_scene(cloud, cam, cov_mode="cov")
+    fw = oracle.forward(sc)
+    ones = torch.ones(n, 3)
+    sc1 = helpers.oracle_scene(cloud, cam, color_mode="precomp", colors=ones, cov_mode="cov")
+    fw1 = oracle.forward(sc1)
+    _bulk_close(pkg.render.detach().cpu().numpy(), fw["color"], name="render")
+    _bulk_close(pkg.opacity_render.detach().cpu().numpy()[0], fw1["color"][0], name="opacity_render")
+    g0 = (np.sign(fw["color"] - gt.cpu().numpy()) / gt.numel()).astype(np.float32)
+    g1 = np.zeros((3, H, W), np.float32)
+    g1[0] = 0.1 * np.sign(fw1["color"][0] - mask.cpu().numpy()[0]) / mask.numel()
+    b0, b1 = oracle.backward(sc, fw, g0), oracle.backward(sc1, fw1, g1)
+    want_m2 = b0["means2D"] + b1["means2D"]
+    _bulk_close(pkg.viewspace_points.grad.cpu().numpy(), want_m2, tol=5e-5, frac=1e-3, name="viewspace grad")
+    assert np.array_equal(pkg.radii.cpu().numpy(), fw["radii"])
+    vf = fw["radii"] > 0
+    assert np.array_equal(pkg.visibility_filter.cpu().numpy(), vf)
+    assert np.array_equal(stats.denom.cpu().numpy()[:, 0], vf.astype(np.float32))
+    assert pc.xyz.grad is not None and torch.isfinite(pc.xyz.grad).all()
+
+
+def test_full_size_properties_config2_50k_512(oracle):
+    """BASELINE config 2 shape (50k Gaussians, 512x512, SH3) through size-independent properties."""
+    from gsplat_mi355 import debug
+    from simple_knn._C import distCUDA2
+    dev = torch.device("cuda:0")
+    n, W, H = 50000, 512, 512
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
+    bg = (0.0, 0.0, 0.0)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    D = st["D"]
+    assert D == int(st["geom"]["tiles_touched"].astype(np.int64).sum()) == len(st["binning"]["point_list"])
+    tiles = st["binning"]["tile_ids"].astype(np.int64)
+    pl = st["binning"]["point_list"]
+    assert (np.diff(tiles) >= 0).all()
+    dbits = st["geom"]["depths"].view(np.uint32)[pl].astype(np.int64)
+    same = tiles[1:] == tiles[:-1]
+    assert (dbits[1:][same] >= dbits[:-1][same]).all()
+    tie = same & (dbits[1:] == dbits[:-1])
+    assert (pl[1:][tie] > pl[:-1][tie]).all()
+    r = st["image"]["ranges"]
+    nz = r[:, 1] > r[:, 0]
+    assert int((r[nz, 1] - r[nz, 0]).sum()) == D
+    counts = np.bincount(tiles, minlength=r.shape[0])
+    assert np.array_equal(counts[nz], (r[nz, 1] - r[nz, 0]))
+    assert np.isfinite(st["color"]).all() and (st["color"] >= 0).all()
+    assert (st["image"]["final_T"] <= 1).all() and (st["image"]["final_T"] > 0).all()
+    # the same scene against the oracle (a few seconds of CPU)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg)
+    fw = oracle.forward(sc)
+    assert np.array_equal(st["radii"], fw["radii"]) and np.array_equal(pl, fw["binning"]["point_list"])
+    _bulk_close(st["color"], fw["color"], name="color 50k/512")
