@@ -10,6 +10,43 @@ void gs_set_error(int hip_err, const char* stage) {
     g_last_stage = stage;
 }
 
+// ---- per-stage event timing -------------------------------------------------------------------
+#include <vector>
+struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfState {
+    bool on = false;
+    bool armed = false;  // the current stage is being timed
+    char filter[32] = {0};
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+// process-wide (autograd runs the backward on its own host thread), guarded by a mutex
+#include <mutex>
+static ProfState g_prof;
+static std::mutex g_prof_mu;
+void gs_prof_begin(const char* stage, hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.armed = g_prof.on && (g_prof.filter[0] == 0 || strcmp(g_prof.filter, stage) == 0);
+    if (!g_prof.armed) return;
+    ProfRec r{stage, g_prof.get(), g_prof.get()};
+    (void)hipEventRecord(r.a, s);
+    g_prof.recs.push_back(r);
+}
+void gs_prof_end(hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.armed || g_prof.recs.empty()) return;
+    (void)hipEventRecord(g_prof.recs.back().b, s);
+    g_prof.armed = false;
+}
+
 static int validate(const GsFwdArgs* a) {
     if (!a) return GS_E_BAD_ARG;
     if (a->P < 0 || a->W <= 0 || a->H <= 0) return GS_E_BAD_ARG;
@@ -70,15 +107,18 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         uint32_t* k1 = (uint32_t*)(g + L.key1);
         uint32_t* v0 = (uint32_t*)(g + L.val0);
         uint32_t* v1 = (uint32_t*)(g + L.val1);
+        { StageScope sc_("preprocess", s);
         rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
-                               (uint32_t*)(g + L.clamped), k0, v0, radii, s);
+                               (uint32_t*)(g + L.clamped), k0, v0, radii, s); }
         if (rc != GS_OK) return rc;
         // stable sort by depth bits: ties keep ascending Gaussian index (the reference's tie order)
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, a->debug, s);
+        { StageScope sc_("depth_sort", s);
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, a->debug, s); }
         if (rc != GS_OK) return rc;
         // 4 passes -> the sorted index ends in (k0, v0)
+        { StageScope sc_("scan", s);
         rc = launch_scan_tiles(v0, (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.tt_rank), (uint32_t*)(g + L.offs),
-                               (uint32_t*)(g + L.bsum), count, a->P, a->debug, s);
+                               (uint32_t*)(g + L.bsum), count, a->P, a->debug, s); }
         if (rc != GS_OK) return rc;
     }
     if (count_host_pinned) {
@@ -110,22 +150,26 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
         uint32_t* k1 = (uint32_t*)(b + B.key1);
         uint32_t* v0 = (uint32_t*)(b + B.val0);
         uint32_t* v1 = (uint32_t*)(b + B.val1);
+        { StageScope sc_("emit", s);
         rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
-                         (float*)(g + L.rec), k0, v0, a->P, I.gx, a->debug, s);
+                         (float*)(g + L.rec), k0, v0, a->P, I.gx, a->debug, s); }
         if (rc != GS_OK) return rc;
         const int bits = tile_bits(ntiles);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, a->debug, s);
+        { StageScope sc_("tile_sort", s);
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, a->debug, s); }
         if (rc != GS_OK) return rc;
         const bool odd = radix_passes(bits) & 1;
         point_list = odd ? v1 : v0;
-        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, a->debug, s);
+        { StageScope sc_("ranges", s);
+        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, a->debug, s); }
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
     }
+    { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, a->bg, a->W, a->H, out_color,
-                               (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s);
+                               (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s); }
     if (rc != GS_OK) return rc;
     if (a->debug) {
         hipError_t e = hipStreamSynchronize(s);
@@ -160,14 +204,16 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         const int bits = tile_bits(I.gx * I.gy);
         const bool odd = radix_passes(bits) & 1;
         const uint32_t* point_list = (const uint32_t*)(b + (odd ? B.val1 : B.val0));
+        { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), a->bg, a->W,
-                                    a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix, (float*)scratch, s);
+                                    a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix, (float*)scratch, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) { gs_set_error((int)e, "render_backward"); return GS_E_HIP; }
         }
     }
+    StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
                                     (const uint32_t*)(g + L.clamped), (const float*)scratch, *gr, s);
 }
@@ -229,6 +275,40 @@ int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
         case 2: *out = m + I.final_T; break;
         default: return GS_E_BAD_ARG;
     }
+    return GS_OK;
+}
+
+int gs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.on = on != 0;
+    return GS_OK;
+}
+int gs_profile_filter(const char* stage) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    memset(g_prof.filter, 0, sizeof(g_prof.filter));
+    if (stage) strncpy(g_prof.filter, stage, sizeof(g_prof.filter) - 1);
+    return GS_OK;
+}
+int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out) {
+    if (max < 0 || !n_out || (max > 0 && (!names || !ms || !launches))) return GS_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof.recs) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+        if (e != hipSuccess) { gs_set_error((int)e, "profile.collect"); t = 0.f; }
+        int k = 0;
+        for (; k < n; k++) if (names[k] == r.name) break;
+        if (k == n) {
+            if (n < max) { names[n] = r.name; ms[n] = 0.f; launches[n] = 0; n++; } else k = -1;
+        }
+        if (k >= 0) { ms[k] += t; launches[k] += 1; }
+        g_prof.pool.push_back(r.a);
+        g_prof.pool.push_back(r.b);
+    }
+    g_prof.recs.clear();
+    *n_out = n;
     return GS_OK;
 }
 

@@ -101,6 +101,15 @@ void gs_set_error(int hip_err, const char* stage);
         if (e__ != hipSuccess) { gs_set_error((int)e__, stage); return GS_E_HIP; }     \
     } while (0)
 
+// Per-stage hipEvent timing (gs_profile_enable / gs_profile_collect); a no-op unless enabled.
+void gs_prof_begin(const char* stage, hipStream_t s);
+void gs_prof_end(hipStream_t s);
+struct StageScope {
+    hipStream_t s;
+    StageScope(const char* stage, hipStream_t st) : s(st) { gs_prof_begin(stage, st); }
+    ~StageScope() { gs_prof_end(s); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Stage launchers (each enqueues on `s`, returns GS_OK / GS_E_HIP)
 // ---------------------------------------------------------------------------------------------

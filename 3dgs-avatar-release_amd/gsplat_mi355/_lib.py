@@ -28,7 +28,7 @@ class GsGrads(ctypes.Structure):
 EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_scratch_bytes",
            "gs_forward_preprocess", "gs_forward_render", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
-           "gs_last_hip_error", "gs_last_stage", "gs_build_info"]
+           "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect"]
 
 _lock = threading.Lock()
 _lib = None
@@ -63,6 +63,9 @@ def load():
         L.gs_geom_field.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        L.gs_profile_enable.argtypes = [c_int]
+        L.gs_profile_filter.argtypes = [c_char_p]
+        L.gs_profile_collect.argtypes = [c_int, POINTER(c_char_p), POINTER(c_float), POINTER(c_int32), POINTER(c_int32)]
         for name in EXPORTS:
             getattr(L, name).restype = c_int
         L.gs_status_string.restype = c_char_p
@@ -80,6 +83,22 @@ def check(rc):
         if rc == -4:
             msg += " %d in stage '%s'" % (L.gs_last_hip_error(), L.gs_last_stage().decode())
         raise RuntimeError("gsplat_mi355: " + msg)
+
+
+def profile_enable(on, stage=None):
+    """Per-stage hipEvent timing on/off; `stage` restricts it to one stage (two events per call)."""
+    check(load().gs_profile_filter(stage.encode() if stage else None))
+    check(load().gs_profile_enable(1 if on else 0))
+
+
+def profile_collect(max_stages=32):
+    """{stage: (total_ms, launches)} since the last collect (waits for the recorded events)."""
+    names = (c_char_p * max_stages)()
+    ms = (c_float * max_stages)()
+    cnt = (c_int32 * max_stages)()
+    n = c_int32(0)
+    check(load().gs_profile_collect(max_stages, names, ms, cnt, ctypes.byref(n)))
+    return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
 
 
 def nbytes(fn, *args):

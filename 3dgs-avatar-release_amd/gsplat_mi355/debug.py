@@ -71,3 +71,17 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
             final_T=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 2), 4 * W * H, np.float32).reshape(H, W),
         )
     return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im)
+
+
+def frame_stats(cam, cloud, pipe, bg):
+    """(num_rendered D, mean n_contrib per pixel) of one frame: reported beside every benchmark number."""
+    import math
+    settings = GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=cloud.sh_degree, campos=cam.camera_center, prefiltered=False,
+        debug=False)
+    with torch.no_grad():
+        st = forward_state(settings, cloud.xyz.detach(), cloud.opacity.detach(), shs=cloud.shs.detach(),
+                           scales=cloud.scales.detach(), rotations=cloud.rotations.detach())
+    return int(st["D"]), float(st["image"]["n_contrib"].mean())

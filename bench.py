@@ -1,0 +1,226 @@
+"""bench.py -- headline benchmark of the MI355X-native Gaussian-splat rasterizer.
+
+Metric (BASELINE.json): render fps (fwd+bwd) @ 200k Gaussians, 1024x1024, SH degree 3.
+A "step" = one pass of the hot path over one frame: rasterizer forward (SH + scale/rotation inputs,
+in-kernel SH->RGB and cov3D), L1 loss against a fixed target (train.py:121 / utils/loss_utils.py:21-22),
+rasterizer backward.  All inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: frames of an orbit sequence are sharded over the ranks (rank r renders frames r, r+N, ...);
+the Gaussian state is built on rank 0 and sent with ONE RCCL broadcast before the timed region; no
+data-path collective per step.  Weak scaling: every rank renders K frames.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "3dgs-avatar-release_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (N, W, H, sh_degree, heavy_tail, backward)
+    "config2": (50000, 512, 512, 3, 0.0, False),
+    "config3": (200000, 1024, 1024, 3, 0.0, True),
+    "config4": (200000, 512, 512, 3, 0.0, True),
+    "config5": (500000, 2048, 2048, 3, 0.05, True),
+    "tiny": (20000, 256, 256, 3, 0.0, True),
+}
+
+
+def stage_bytes(N, D, px, sh=True):
+    """ALGORITHMIC (compulsory) bytes per launch group, SURVEY.md 8(d): B_in = 236 (SH3 + scale/rot),
+    B_state = 79, B_grad = 248."""
+    B_in, B_state, B_grad = (236 if sh else 52), 79, 248
+    return {
+        "preprocess": N * (B_in + 4 + B_state),
+        "binning": D * (12 + 12),
+        "render_fwd": D * 40 + px * (12 + 8),
+        "render_bwd": px * (12 + 8) + D * (4 + 40) + D * 36,
+        "gaussian_bwd": N * (B_in + B_state + 40 + B_grad),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gsplat_mi355 import _lib
+    from gsplat_mi355.camera import orbit_camera
+    from gsplat_mi355.render import Pipe, l1_loss, render
+    from gsplat_mi355.scenes import GaussianCloud, synthetic_cloud
+    from gsplat_mi355.sharding import broadcast_cloud, frames_of_rank
+
+    _lib.load()
+    N, W, H, deg, tail, do_bwd = WORKLOADS[args.workload]
+
+    # ---- Gaussian state: built on rank 0, one RCCL broadcast
+    cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev) if rank == 0 else None
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cloud = broadcast_cloud(cloud, N, deg, dev, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    for f in GaussianCloud.FIELDS:
+        getattr(cloud, f).requires_grad_(do_bwd)
+
+    K, Wm = args.steps, args.warmup
+    frames = frames_of_rank(rank, world, K + Wm + 8)
+    cams = [orbit_camera(f, W, H, device=dev) for f in frames]
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    bg = torch.zeros(3, device=dev)
+    pipe = Pipe(compute_cov3D_python=False)
+
+    def step(i):
+        for f in GaussianCloud.FIELDS:
+            getattr(cloud, f).grad = None
+        if do_bwd:
+            pkg = render(cams[i], cloud, pipe, bg)
+            loss = l1_loss(pkg.render, gt)
+            loss.backward()
+        else:
+            with torch.no_grad():
+                pkg = render(cams[i], cloud, pipe, bg)
+        return pkg
+
+    # ---- untimed: a few steps with every stage bracketed by HIP events -> dominant kernel
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for i in range(3, 8):
+        pkg = step(i)
+    stages = _lib.profile_collect()
+    _lib.profile_enable(False)
+    stage_ms = {k: v[0] / 5.0 for k, v in stages.items()}  # ms per frame (5 profiled frames)
+    groups = {"preprocess": ["preprocess"], "binning": ["depth_sort", "scan", "emit", "tile_sort", "ranges"],
+              "render_fwd": ["render_fwd"], "render_bwd": ["render_bwd"], "gaussian_bwd": ["gaussian_bwd"]}
+    kernel_stages = ["preprocess", "render_fwd", "render_bwd", "gaussian_bwd"]
+    dominant = max(kernel_stages, key=lambda k: stage_ms.get(k, 0.0))
+
+    # D and n_contrib of the benchmark frame (reported with every number: cost is a function of D)
+    with torch.no_grad():
+        vis = int((pkg.radii > 0).sum().item())
+    from gsplat_mi355.debug import frame_stats
+    D, mean_contrib = frame_stats(cams[0], cloud, pipe, bg)
+
+    # ---- warmup + timed region
+    for i in range(Wm):
+        step(8 + i)
+    _lib.profile_enable(True, stage=dominant)  # two HIP events per step around the dominant kernel only
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(8 + Wm + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dom = _lib.profile_collect().get(dominant, (0.0, 0))
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        px = W * H
+        sb = stage_bytes(N, D, px)
+        dom_ms = dom[0] / max(dom[1], 1)
+        achieved = sb[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        frame_bytes = sum(sb.values()) if do_bwd else sb["preprocess"] + sb["binning"] + sb["render_fwd"]
+        fps = world * K / elapsed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "render fps (fwd+bwd) @200k Gaussians 1024x1024 SH3" if args.workload == "config3"
+            else "render fps (%s) @%s" % ("fwd+bwd" if do_bwd else "fwd", args.workload),
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, L1 loss" % (
+                args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward"),
+                "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
+                "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
+                "broadcast_s": round(t_bcast, 6)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
+                         "frame_algorithmic_bytes": frame_bytes,
+                         "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {g: round(sum(stage_ms.get(s, 0.0) for s in ss), 4) for g, ss in groups.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cloud, W, H, deg, gt, do_bwd, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cloud, W, H, deg, gt, do_bwd, threads):
+    """The CPU oracle (oracle/gs_oracle.c, kind 'port': the reference has no CPU path and its CUDA
+    source is absent) timed on the host cores on ONE frame of the same workload."""
+    ncpu = len(os.sched_getaffinity(0))
+    nthr = threads if threads > 0 else min(ncpu, 16)
+    import helpers
+    from gsplat_mi355.camera import orbit_camera
+    from gsplat_mi355.scenes import GaussianCloud
+    from oracle import gs_oracle
+    gs_oracle.build()
+    gs_oracle.set_num_threads(nthr)
+    c = GaussianCloud(*[getattr(cloud, f).detach().cpu() for f in GaussianCloud.FIELDS], deg)
+    cam = orbit_camera(0, W, H)
+    sc = helpers.oracle_scene(c, cam)
+    t0 = time.perf_counter()
+    fw = gs_oracle.forward(sc)
+    if do_bwd:
+        g = (np.sign(fw["color"] - gt.cpu().numpy()) / gt.numel()).astype(np.float32)
+        gs_oracle.backward(sc, fw, g)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": gs_oracle.num_threads(), "kind": "port",
+            "sample": "1 frame (%s) of the same scene, %.1f s of wall time" % ("fwd+bwd" if do_bwd else "fwd", dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,15 @@ int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
 int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
 
+/* ---- per-stage timing (the reference only timed whole calls with CUDA events: render.py:46-62,
+ * train.py:79-88,181-185).  When enabled (process-wide: autograd runs the backward on its own host thread), every stage launched by this library is
+ * bracketed by a pair of hipEvents recorded ON THE STAGE'S OWN STREAM.  gs_profile_collect waits for
+ * the recorded events, sums the elapsed milliseconds and launch counts per stage name (first `max`
+ * distinct stages, names are static strings) and clears the record. ---- */
+int gs_profile_enable(int on);
+int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
+int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
+
 const char* gs_status_string(int code);
 int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */
 const char* gs_last_stage(void); /* name of the stage that failed (debug mode names every kernel) */

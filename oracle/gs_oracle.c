@@ -616,6 +616,15 @@ int or_dist2(int P, const float* pts, float* out) {
     return 0;
 }
 
+void or_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int or_num_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

@@ -210,5 +210,9 @@ def dist2(points):
     return out
 
 
+def set_num_threads(n):
+    lib().or_set_num_threads(c_int(int(n)))
+
+
 def num_threads():
     return int(lib().or_num_threads())
