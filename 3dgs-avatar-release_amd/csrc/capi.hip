@@ -82,9 +82,9 @@ int gs_binning_bytes(int64_t D, int32_t W, int32_t H, size_t* out) {
     *out = bin_layout(D).total;
     return GS_OK;
 }
-int gs_backward_scratch_bytes(int64_t D, size_t* out) {
-    if (!out || D < 0) return GS_E_BAD_ARG;
-    *out = align_up((size_t)(D > 0 ? D : 1) * REC_F * 4, 256);
+int gs_backward_scratch_bytes(int64_t D, int32_t P, size_t* out) {
+    if (!out || D < 0 || P < 0) return GS_E_BAD_ARG;
+    *out = scratch_total_bytes(D, P);
     return GS_OK;
 }
 
@@ -183,7 +183,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
                 const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {
     int rc = validate(a);
     if (rc != GS_OK) return rc;
-    if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && (!binning || !scratch))) return GS_E_BAD_ARG;
+    if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch)) return GS_E_BAD_ARG;
     if (a->P > 0 && (!radii || !gr->dL_dmeans3D || !gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dcov3D))
         return GS_E_BAD_ARG;
     if (a->P > 0 && a->shs && !gr->dL_dsh) return GS_E_BAD_ARG;
@@ -192,8 +192,8 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     const ImgLayout I = img_layout(a->W, a->H);
     const BinLayout B = bin_layout(D);
     size_t need = 0;
-    gs_backward_scratch_bytes(D, &need);
-    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && (binning_bytes < B.total || scratch_bytes < need)))
+    gs_backward_scratch_bytes(D, a->P, &need);
+    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total) || (a->P > 0 && scratch_bytes < need))
         return GS_E_WORKSPACE;
     if (a->P == 0) return GS_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -215,7 +215,8 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     }
     StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
-                                    (const uint32_t*)(g + L.clamped), (const float*)scratch, *gr, s);
+                                    (const uint32_t*)(g + L.clamped), (const float*)scratch,
+                                    (float*)((char*)scratch + scratch_rows_bytes(D)), *gr, s);
 }
 
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

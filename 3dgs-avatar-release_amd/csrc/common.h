@@ -40,7 +40,7 @@ static inline GeomLayout geom_layout(int P) {
     L.tt_rank = take(n * 4);
     L.offs = take(n * 4);
     L.bsum = take((size_t)(L.nblk_scan + 1) * 4);
-    L.hist = take((size_t)256 * L.nblk_sort * 4);
+    L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
     L.count = take(64);
     L.total = o;
     return L;
@@ -60,7 +60,7 @@ static inline BinLayout bin_layout(int64_t D) {
     L.key1 = take(n * 4);
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
-    L.hist = take((size_t)256 * L.nblk_sort * 4);
+    L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
     L.total = o;
     return L;
 }
@@ -134,7 +134,13 @@ int launch_render_backward(const float* rec, const uint32_t* point_list, const u
                            int H, const uint32_t* n_contrib, const float* out_color, const float* dL_dpix,
                            float* entry_grads, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const float* entry_grads, const GsGrads& g, hipStream_t s);
+                             const uint32_t* clamped, const float* entry_grads, float* sums, const GsGrads& g,
+                             hipStream_t s);
+// backward scratch: [D rows x 48 B of per-pair gradients | P rows x 48 B of per-Gaussian sums]
+static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * REC_F * 4, 256); }
+static inline size_t scratch_total_bytes(int64_t D, int P) {
+    return scratch_rows_bytes(D) + align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256);
+}
 
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_ws_bytes(int P);

@@ -5,28 +5,25 @@
 // is written in full (zeros for culled Gaussians), so the caller passes un-initialised tensors.
 #include "common.h"
 #include "gs_math.h"
+#include "blend.h"
 
-__global__ __launch_bounds__(256) void gaussian_bwd_kernel(
-    int P, int deg, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
-    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
-    int H, float tanfovx, float tanfovy, float fx, float fy, const int32_t* __restrict__ radii,
-    const float4* __restrict__ rec, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ clamped,
-    const float4* __restrict__ entry_grads, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
-    float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const bool live = radii[i] > 0;
-
-    // ---- segmented sum of the nine 2-D gradients over this Gaussian's (tile, Gaussian) pairs ----
+// Segmented sum of the per-pair gradient rows: 8 lanes per Gaussian walk its contiguous segment
+// (8 consecutive 48-byte rows per step), then fold with three DPP adds.  sums[i] = 12 floats.
+__global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
+                                                             const float4* __restrict__ rec,
+                                                             const uint32_t* __restrict__ tiles,
+                                                             const float4* __restrict__ entry_grads,
+                                                             float4* __restrict__ sums) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 3, j = t & 7;
     float s[9];
 #pragma unroll
     for (int c = 0; c < 9; c++) s[c] = 0.f;
-    if (live) {
+    const bool in = i < P;
+    if (in && radii[i] > 0) {
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
         const uint32_t tt = tiles[i];
-        for (uint32_t k = 0; k < tt; k++) {
+        for (uint32_t k = j; k < tt; k += 8) {
             const float4 e0 = entry_grads[(size_t)(off + k) * 3];
             const float4 e1 = entry_grads[(size_t)(off + k) * 3 + 1];
             const float e2 = entry_grads[(size_t)(off + k) * 3 + 2].x;
@@ -34,6 +31,42 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
             s[4] += e1.x; s[5] += e1.y; s[6] += e1.z; s[7] += e1.w;
             s[8] += e2;
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        float v = s[c];
+        v += dpp_get<0xB1, 0xF>(v);   // lane ^ 1
+        v += dpp_get<0x4E, 0xF>(v);   // lane ^ 2
+        v += dpp_get<0x141, 0xF>(v);  // row_half_mirror: lane <-> 7 - lane inside each group of 8
+        s[c] = v;
+    }
+    if (in && j < 3) {
+        const float4 o = (j == 0) ? make_float4(s[0], s[1], s[2], s[3])
+                                  : (j == 1) ? make_float4(s[4], s[5], s[6], s[7]) : make_float4(s[8], 0.f, 0.f, 0.f);
+        sums[(size_t)i * 3 + j] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gaussian_bwd_kernel(
+    int P, int deg, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
+    int H, float tanfovx, float tanfovy, float fx, float fy, const int32_t* __restrict__ radii,
+    const uint32_t* __restrict__ clamped, const float4* __restrict__ sums, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool live = radii[i] > 0;
+
+    // ---- the nine 2-D gradient sums of this Gaussian (segment_reduce_kernel) ----
+    float s[9];
+    {
+        const float4 a0 = sums[(size_t)i * 3], a1 = sums[(size_t)i * 3 + 1];
+        const float a2 = sums[(size_t)i * 3 + 2].x;
+        s[0] = a0.x; s[1] = a0.y; s[2] = a0.z; s[3] = a0.w;
+        s[4] = a1.x; s[5] = a1.y; s[6] = a1.z; s[7] = a1.w;
+        s[8] = a2;
     }
     const float g2x = s[0] * (0.5f * W), g2y = s[1] * (0.5f * H);  // d/d(NDC): pixel gradient * 0.5 * (W, H)
     const float gA = s[2], gB = s[3], gC = s[4], gO = s[5];
@@ -232,12 +265,17 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 }
 
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const float* entry_grads, const GsGrads& g, hipStream_t s) {
+                             const uint32_t* clamped, const float* entry_grads, float* sums, const GsGrads& g,
+                             hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
+    hipLaunchKernelGGL(segment_reduce_kernel, dim3((a.P * 8 + 255) / 256), dim3(256), 0, s, a.P, radii,
+                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const float4*>(entry_grads),
+                       reinterpret_cast<float4*>(sums));
+    GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
     hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D,
                        a.scales, a.scale_modifier, a.rotations, a.shs, a.cov3D_precomp, a.viewmatrix, a.projmatrix,
-                       a.campos, a.W, a.H, a.tanfovx, a.tanfovy, fx, fy, radii, reinterpret_cast<const float4*>(rec),
-                       tiles, clamped, reinterpret_cast<const float4*>(entry_grads), g.dL_dmeans3D, g.dL_dmeans2D,
+                       a.campos, a.W, a.H, a.tanfovx, a.tanfovy, fx, fy, radii, clamped,
+                       reinterpret_cast<const float4*>(sums), g.dL_dmeans3D, g.dL_dmeans2D,
                        g.dL_dsh, g.dL_dcolors, g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D);
     GS_LAUNCH_CHECK("gaussian_backward", a.debug, s);
     return GS_OK;

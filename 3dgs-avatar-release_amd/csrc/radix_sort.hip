@@ -11,7 +11,8 @@
 #define RS_ROUNDS (SORT_ITEMS / RS_THREADS)
 
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
-                                                             uint32_t* __restrict__ hist, int nblk) {
+                                                             uint32_t* __restrict__ hist, int nblk,
+                                                             uint32_t* __restrict__ totals) {
     __shared__ uint32_t h[256];
     const int tid = threadIdx.x;
     h[tid] = 0;
@@ -24,42 +25,42 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     }
     __syncthreads();
     hist[(size_t)tid * nblk + blockIdx.x] = h[tid];
+    if (h[tid]) atomicAdd(&totals[tid], h[tid]);
 }
 
-// exclusive scan of `m` u32 values in place, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ data, int64_t m) {
-    __shared__ uint32_t wsum[16];
+// Exclusive scan of the digit-major [256][nblk] table, one workgroup per digit: block d adds the
+// total of every smaller digit (from `totals`, accumulated by the histogram kernel) to the running
+// prefix of its own row.
+__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ hist, int nblk,
+                                                      const uint32_t* __restrict__ totals) {
+    __shared__ uint32_t ws[4];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    const int d = blockIdx.x;
+    uint32_t v = (tid < d) ? totals[tid] : 0u;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
+    if (lane == 0) ws[wid] = v;
     __syncthreads();
-    for (int64_t base = 0; base < m; base += 4096) {
-        // 4 consecutive items per thread
-        uint32_t v[4];
-        const int64_t i0 = base + (int64_t)tid * 4;
+    if (tid == 0) carry_s = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    uint32_t* row = hist + (size_t)d * nblk;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + tid;
+        const uint32_t x0 = i < nblk ? row[i] : 0u;
+        uint32_t x = x0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k < m) ? data[i0 + k] : 0u;
-        uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-        // wave inclusive scan
-        uint32_t x = tsum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
+        for (int k = 1; k < 64; k <<= 1) {
+            uint32_t y = __shfl_up(x, k, 64);
+            if (lane >= k) x += y;
         }
-        if (lane == 63) wsum[wid] = x;
+        if (lane == 63) ws[wid] = x;
         __syncthreads();
         uint32_t woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        uint32_t total = 0;
-        for (int w = 0; w < 16; w++) total += wsum[w];
+        for (int w = 0; w < wid; w++) woff += ws[w];
+        const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
         const uint32_t carry = carry_s;
-        uint32_t excl = carry + woff + x - tsum;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < m) data[i0 + k] = excl;
-            excl += v[k];
-        }
+        if (i < nblk) row[i] = carry + woff + x - x0;
         __syncthreads();
         if (tid == 0) carry_s = carry + total;
         __syncthreads();
@@ -118,12 +119,17 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, ui
     if (n <= 0) return GS_OK;
     const int nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
     const int passes = radix_passes(bits);
+    // per-pass digit totals live behind the [256][nblk] table (the layouts reserve 4 x 256 extra words)
+    uint32_t* totals = hist + (size_t)256 * nblk;
+    hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
+    if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblk);
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblk,
+                           totals + 256 * p);
         GS_LAUNCH_CHECK("sort.hist", debug, s);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * nblk);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, hist, nblk, totals + 256 * p);
         GS_LAUNCH_CHECK("sort.scan", debug, s);
         hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblk);
         GS_LAUNCH_CHECK("sort.scatter", debug, s);
