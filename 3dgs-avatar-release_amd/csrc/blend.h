@@ -1,16 +1,65 @@
 // blend.h -- the per-(pixel, Gaussian) evaluation shared by the forward and backward render
-// kernels (they must take identical skip decisions), and wave64 reduction helpers.
+// kernels (they must take identical skip decisions), per-(tile, Gaussian) staging, and wave64
+// reduction helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
-// alpha of one Gaussian at one pixel: d = centre - pixel,
-// power = -0.5 (A dx^2 + C dy^2) - B dx dy; rejected if power > 0 or alpha < 1/255.
-// G = exp(power) is returned for the backward pass.
-__device__ __forceinline__ bool splat_alpha(float dx, float dy, float A, float B, float C, float o, float& alpha,
-                                            float& G) {
-    const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
-    if (power > 0.0f) return false;
-    G = __expf(power);
+#define LOG2E_F 1.4426950408889634f
+
+// ---------------------------------------------------------------------------------------------
+// Tile ownership: one wave64 per 16x16 tile; the tile is four 8x8 QUADRANTS, lane l owns pixel
+// (l & 7, l >> 3) of every quadrant, quadrant q sits at (8 * (q & 1), 8 * (q >> 1)).
+// ---------------------------------------------------------------------------------------------
+
+// A staged (tile, Gaussian) entry: 48 bytes in LDS, read at a wave-uniform address.
+//   a = (x, y, A2, B2)   centre in pixels; conic pre-scaled into the log2 domain:
+//                        power2 = A2 dx^2 + C2 dy^2 + B2 dx dy = log2(e) * power
+//   b = (C2, opacity, thr, quadrant mask bits)
+//   c = (r, g, b, row index of the pair in emission order (backward only))
+struct Staged {
+    float4 a, b, c;
+};
+
+// Builds the staged entry from a splat record (r0, r1, r2 as written by the preprocess kernel).
+// `thr`: alpha >= 1/255  <=>  opacity * 2^power2 >= 1/255  <=>  power2 >= -log2(255 * opacity); kept
+// slightly relaxed (-1e-3) and used only as a cheap early reject -- the decision itself is still
+// taken on alpha.  Quadrant mask: bit q set iff the axis-aligned bounding box of the ellipse
+// {power2 >= thr} (half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) with cov = conic^-1 and
+// 2 tau = -2 thr / log2 e) reaches a pixel centre of quadrant q.  Conservative by a 1e-4 relative +
+// 0.01 px margin, so culled quadrants hold only pairs the per-pixel test would reject anyway.
+__device__ __forceinline__ Staged stage_entry(const float4 r0, const float4 r1, const float4 r2, int X0, int Y0) {
+    Staged s;
+    const float gx = r0.x, gy = r0.y, A = r0.z, B = r0.w, C = r1.x, o = r1.y;
+    const float thr = -__log2f(255.f * o) - 1e-3f;
+    uint32_t mask = 0;
+    if (thr <= 0.f) {
+        const float det = A * C - B * B;
+        if (det > 0.f) {
+            const float two_tau = (-2.f / LOG2E_F) * thr;
+            const float k = two_tau / det;
+            const float ex = sqrtf(k * C) * 1.0001f + 0.01f;
+            const float ey = sqrtf(k * A) * 1.0001f + 0.01f;
+            const float x0 = gx - ex - (float)X0, x1 = gx + ex - (float)X0;
+            const float y0 = gy - ey - (float)Y0, y1 = gy + ey - (float)Y0;
+            const bool cx0 = (x1 >= 0.f) && (x0 <= 7.f), cx1 = (x1 >= 8.f) && (x0 <= 15.f);
+            const bool cy0 = (y1 >= 0.f) && (y0 <= 7.f), cy1 = (y1 >= 8.f) && (y0 <= 15.f);
+            mask = (cx0 && cy0 ? 1u : 0u) | (cx1 && cy0 ? 2u : 0u) | (cx0 && cy1 ? 4u : 0u) | (cx1 && cy1 ? 8u : 0u);
+        } else {
+            mask = 0xFu;
+        }
+    }
+    s.a = make_float4(gx, gy, (-0.5f * LOG2E_F) * A, -LOG2E_F * B);
+    s.b = make_float4((-0.5f * LOG2E_F) * C, o, thr, __uint_as_float(mask));
+    s.c = make_float4(r1.z, r1.w, r2.x, 0.f);
+    return s;
+}
+
+// alpha of one Gaussian at one pixel in the log2 domain.  Rejected if
+// power > 0 or alpha < 1/255.  G = exp(power) is returned for the backward pass.
+__device__ __forceinline__ bool splat_alpha2(float power2, float o, float thr, float& alpha, float& G) {
+    if (power2 > 0.0f || power2 < thr) return false;
+    G = __builtin_amdgcn_exp2f(power2);
     alpha = fminf(0.99f, o * G);
     return alpha >= (1.0f / 255.0f);
 }

@@ -26,13 +26,12 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         float4* __restrict__ entry_grads) {
     __shared__ float4 srec[64 * 3];
     __shared__ float4 srow[64 * 3];
-    __shared__ uint32_t sq[64];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
-    const int lx = lane & 15, ly = lane >> 4;
-    const int px = tx * TILE + lx, py0 = ty * TILE + ly * 4;
-    const float pxf = (float)px;
+    const int X0 = tx * TILE, Y0 = ty * TILE;
+    const int px0 = X0 + (lane & 7), py0 = Y0 + (lane >> 3);
+    const float pxf = (float)px0, pyf = (float)py0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n == 0) return;
@@ -40,12 +39,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
     float T[4], Pfx[4], Gtot[4], g[4][3];
     uint32_t ncon[4];
-    uint32_t my_max = 0;
+    uint32_t qmax[4];  // wave-uniform: entries >= qmax[k] contribute to no pixel of quadrant k
+    uint32_t nmax_u = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         T[k] = 1.0f;
         Pfx[k] = 0.f;
-        const int py = py0 + k;
+        const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
         if (px < W && py < H) {
             const size_t pid = (size_t)py * W + px;
             g[k][0] = dL_dpix[pid];
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             Gtot[k] = 0.f;
             ncon[k] = 0;
         }
-        my_max = max(my_max, ncon[k]);
+        qmax[k] = __builtin_amdgcn_readfirstlane(wave_max_u32(ncon[k]));
+        nmax_u = max(nmax_u, qmax[k]);
     }
-    const int nmax = (int)wave_max_u32(my_max);  // entries >= nmax contribute to no pixel of the tile
+    const int nmax = (int)nmax_u;  // entries >= nmax contribute to no pixel of the tile
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     if (lane < nmax) {
@@ -73,18 +74,19 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     for (int base = 0; base < nmax; base += 64) {
         const int cnt = min(64, nmax - base);
         __syncthreads();
-        srec[lane * 3] = p0;
-        srec[lane * 3 + 1] = p1;
-        srec[lane * 3 + 2] = p2;
-        srow[lane * 3] = zero4;
-        srow[lane * 3 + 1] = zero4;
-        srow[lane * 3 + 2] = zero4;
         {
+            Staged s = stage_entry(p0, p1, p2, X0, Y0);
             // row index of this pair in emission order: first pair of the Gaussian + position of this
             // tile inside the Gaussian's rectangle (y outer, x inner)
             const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
             const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
-            sq[lane] = off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx);
+            s.c.w = __uint_as_float(off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx));
+            srec[lane * 3] = s.a;
+            srec[lane * 3 + 1] = s.b;
+            srec[lane * 3 + 2] = s.c;
+            srow[lane * 3] = zero4;
+            srow[lane * 3 + 1] = zero4;
+            srow[lane * 3 + 2] = zero4;
         }
         __syncthreads();
         if (base + 64 + lane < nmax) {
@@ -94,54 +96,78 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             p2 = rec[(size_t)id * 3 + 2];
         }
         for (int j = 0; j < cnt; j++) {
-            const float4 a = srec[j * 3], b = srec[j * 3 + 1];
-            const float cz = srec[j * 3 + 2].x;
-            const float dx = a.x - pxf;
             const uint32_t entry = (uint32_t)(base + j);
+            const float4 b = srec[j * 3 + 1];
+            uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (entry >= qmax[k]) m &= ~(1u << k);
+            if (m == 0) continue;
+            const float4 a = srec[j * 3];
+            const float4 c = srec[j * 3 + 2];
+            float dx[2], dy[2], ax[2], cy[2], bx[2];
+            dx[0] = a.x - pxf;
+            dx[1] = dx[0] - 8.f;
+            dy[0] = a.y - pyf;
+            dy[1] = dy[0] - 8.f;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                ax[h] = a.z * dx[h] * dx[h];
+                cy[h] = b.x * dy[h] * dy[h];
+                bx[h] = a.w * dx[h];
+            }
+            // accumulators (constant factors applied after the reduction):
+            //  0: sum t*u   u = 2 A2 dx + B2 dy   -> dL/dmean.x = acc0 / log2e
+            //  1: sum t*v   v = 2 C2 dy + B2 dx   -> dL/dmean.y = acc1 / log2e
+            //  2: sum t*dx^2  3: sum t*dx*dy  4: sum t*dy^2   (t = G dL/dG)  -> dL/dconic = -0.5 * acc
+            //  5: sum G dL/dalpha   6..8: sum w g_c
             float acc[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) acc[c] = 0.f;
+            for (int q = 0; q < 9; q++) acc[q] = 0.f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (!(m & (1u << k))) continue;  // wave-uniform
                 if (entry >= ncon[k]) continue;
-                const float dy = a.y - (float)(py0 + k);
+                const float ddx = dx[k & 1], ddy = dy[k >> 1];
+                const float power2 = bx[k & 1] * ddy + (ax[k & 1] + cy[k >> 1]);
                 float alpha, G;
-                if (!splat_alpha(dx, dy, a.z, a.w, b.x, b.y, alpha, G)) continue;
+                if (!splat_alpha2(power2, b.y, b.z, alpha, G)) continue;
                 any = true;
                 const float w = alpha * T[k];
-                const float cg = b.z * g[k][0] + b.w * g[k][1] + cz * g[k][2];
+                const float cg = c.x * g[k][0] + c.y * g[k][1] + c.z * g[k][2];
                 Pfx[k] += cg * w;
                 const float one_m = 1.f - alpha;
-                const float dL_dalpha = T[k] * cg - (Gtot[k] - Pfx[k]) / one_m;
+                const float dL_dalpha = T[k] * cg - (Gtot[k] - Pfx[k]) * __builtin_amdgcn_rcpf(one_m);
                 T[k] *= one_m;
                 acc[6] += w * g[k][0];
                 acc[7] += w * g[k][1];
                 acc[8] += w * g[k][2];
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                acc[0] += dL_dG * dG_ddelx;
-                acc[1] += dL_dG * dG_ddely;
-                acc[2] += -0.5f * gdx * dx * dL_dG;
-                acc[3] += -0.5f * gdx * dy * dL_dG;
-                acc[4] += -0.5f * gdy * dy * dL_dG;
-                acc[5] += G * dL_dalpha;
+                const float Gd = G * dL_dalpha;
+                const float t = b.y * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
+                const float u = 2.f * a.z * ddx + a.w * ddy;
+                const float v = 2.f * b.x * ddy + a.w * ddx;
+                acc[0] += t * u;
+                acc[1] += t * v;
+                acc[2] += t * ddx * ddx;
+                acc[3] += t * ddx * ddy;
+                acc[4] += t * ddy * ddy;
+                acc[5] += Gd;
             }
             if (__ballot(any) != 0ull) {
 #pragma unroll
-                for (int c = 0; c < 9; c++) acc[c] = wave_sum_to_lane63(acc[c]);
+                for (int q = 0; q < 9; q++) acc[q] = wave_sum_to_lane63(acc[q]);
                 if (lane == 63) {
-                    srow[j * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    srow[j * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    const float il2 = 1.0f / LOG2E_F;
+                    srow[j * 3] = make_float4(acc[0] * il2, acc[1] * il2, -0.5f * acc[2], -0.5f * acc[3]);
+                    srow[j * 3 + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
                     srow[j * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
                 }
             }
         }
         __syncthreads();
         if (lane < cnt) {
-            const size_t q = sq[lane];
+            const size_t q = __float_as_uint(srec[lane * 3 + 2].w);
             entry_grads[q * 3] = srow[lane * 3];
             entry_grads[q * 3 + 1] = srow[lane * 3 + 1];
             entry_grads[q * 3 + 2] = srow[lane * 3 + 2];

@@ -1,12 +1,14 @@
 // render_fwd.hip -- per-tile front-to-back alpha compositing (replaces
 // upstream renderCUDA forward).
 //
-// CDNA4 mapping: ONE wave64 owns one 16x16 tile; lane (lx = lane & 15, ly = lane >> 4) owns the
-// four vertically adjacent pixels (16*tx + lx, 16*ty + 4*ly + k), k = 0..3.  The tile's depth-ordered
-// list is staged 64 splat records (48 B each, gathered by the 64 lanes in parallel, next batch
-// prefetched into registers) at a time through LDS; the inner loop reads one record per
-// iteration at a wave-uniform LDS address (broadcast) and amortises it over the lane's 4 pixels.
-// No workgroup barrier spans more than this one wave, and the early-out is a wave ballot.
+// CDNA4 mapping: ONE wave64 owns one 16x16 tile, as four 8x8 quadrants; lane l owns pixel
+// (l & 7, l >> 3) of each quadrant, so one wave-uniform read of a staged entry serves 256 pixels.
+// The tile's depth-ordered list is staged 64 entries at a time: each lane gathers one 48-byte splat
+// record (the next batch is prefetched into registers), converts it (log2-domain conic, alpha
+// threshold, QUADRANT MASK = which 8x8 quadrants the Gaussian's alpha >= 1/255 footprint can reach)
+// and parks it in LDS.  The inner loop then runs only the quadrants in the mask that still have a
+// live pixel -- a wave-uniform (scalar) branch, so skipped quadrants cost nothing.
+// No workgroup barrier spans more than this one wave; the early-out is a wave ballot.
 #include "common.h"
 #include "blend.h"
 
@@ -19,24 +21,25 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
-    const int lx = lane & 15, ly = lane >> 4;
-    const int px = tx * TILE + lx, py0 = ty * TILE + ly * 4;
-    const float pxf = (float)px;
+    const int X0 = tx * TILE, Y0 = ty * TILE;
+    const int px0 = X0 + (lane & 7), py0 = Y0 + (lane >> 3);
+    const float pxf = (float)px0, pyf = (float)py0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
     float T[4], C[4][3];
     uint32_t last[4];
     bool done[4];
+    uint32_t qlive = 0;  // wave-uniform: quadrants that still have a pixel accepting contributions
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         T[k] = 1.0f;
         C[k][0] = C[k][1] = C[k][2] = 0.f;
         last[k] = 0;
-        done[k] = !(px < W && (py0 + k) < H);
+        done[k] = !((px0 + 8 * (k & 1)) < W && (py0 + 8 * (k >> 1)) < H);
+        if (__ballot(!done[k]) != 0ull) qlive |= 1u << k;
     }
 
-    // prefetch batch 0
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     if (lane < n) {
         const uint32_t id = point_list[range.x + lane];
@@ -44,14 +47,15 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         p1 = rec[(size_t)id * 3 + 1];
         p2 = rec[(size_t)id * 3 + 2];
     }
-    for (int base = 0; base < n; base += 64) {
-        const bool lane_live = !(done[0] && done[1] && done[2] && done[3]);
-        if (__ballot(lane_live) == 0ull) break;
+    for (int base = 0; base < n && qlive != 0; base += 64) {
         const int cnt = min(64, n - base);
         __syncthreads();
-        srec[lane * 3] = p0;
-        srec[lane * 3 + 1] = p1;
-        srec[lane * 3 + 2] = p2;
+        {
+            const Staged s = stage_entry(p0, p1, p2, X0, Y0);
+            srec[lane * 3] = s.a;
+            srec[lane * 3 + 1] = s.b;
+            srec[lane * 3 + 2] = s.c;
+        }
         __syncthreads();
         if (base + 64 + lane < n) {
             const uint32_t id = point_list[range.x + base + 64 + lane];
@@ -60,32 +64,53 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             p2 = rec[(size_t)id * 3 + 2];
         }
         for (int j = 0; j < cnt; j++) {
-            const float4 a = srec[j * 3], b = srec[j * 3 + 1];
-            const float cz = srec[j * 3 + 2].x;
-            const float dx = a.x - pxf;
+            const float4 b = srec[j * 3 + 1];
+            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w)) & qlive;
+            if (m == 0) continue;
+            const float4 a = srec[j * 3];
+            const float4 c = srec[j * 3 + 2];
             const uint32_t contributor = (uint32_t)(base + j + 1);
+            float dx[2], dy[2], ax[2], cy[2], bx[2];
+            dx[0] = a.x - pxf;
+            dx[1] = dx[0] - 8.f;
+            dy[0] = a.y - pyf;
+            dy[1] = dy[0] - 8.f;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                ax[h] = a.z * dx[h] * dx[h];
+                cy[h] = b.x * dy[h] * dy[h];
+                bx[h] = a.w * dx[h];
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (done[k]) continue;
-                const float dy = a.y - (float)(py0 + k);
-                float alpha, G;
-                if (!splat_alpha(dx, dy, a.z, a.w, b.x, b.y, alpha, G)) continue;
-                const float test_T = T[k] * (1.f - alpha);
-                if (test_T < 0.0001f) { done[k] = true; continue; }
-                const float w = alpha * T[k];
-                C[k][0] += b.z * w;
-                C[k][1] += b.w * w;
-                C[k][2] += cz * w;
-                T[k] = test_T;
-                last[k] = contributor;
+                if (!(m & (1u << k))) continue;  // wave-uniform
+                if (!done[k]) {
+                    const float power2 = bx[k & 1] * dy[k >> 1] + (ax[k & 1] + cy[k >> 1]);
+                    float alpha, G;
+                    if (splat_alpha2(power2, b.y, b.z, alpha, G)) {
+                        const float test_T = T[k] * (1.f - alpha);
+                        if (test_T < 0.0001f) {
+                            done[k] = true;
+                        } else {
+                            const float w = alpha * T[k];
+                            C[k][0] += c.x * w;
+                            C[k][1] += c.y * w;
+                            C[k][2] += c.z * w;
+                            T[k] = test_T;
+                            last[k] = contributor;
+                        }
+                    }
+                }
+                if (__ballot(!done[k]) == 0ull) qlive &= ~(1u << k);
             }
+            if (qlive == 0) break;
         }
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int py = py0 + k;
+        const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
         if (px < W && py < H) {
             const size_t pid = (size_t)py * W + px;
             final_T[pid] = T[k];
