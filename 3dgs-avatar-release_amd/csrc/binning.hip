@@ -175,3 +175,64 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int 
     }
     return GS_OK;
 }
+
+// Launch order of the per-tile render waves: tiles sorted by DESCENDING work estimate (a counting
+// sort into 1024 bins of work / max_work; ties in any order).  All tile waves of a frame are
+// resident at once and the hardware deals workgroups breadth-first over the SIMDs, so handing out
+// the tiles heaviest-first gives every SIMD one tile from each work quantile -- the kernel then
+// ends with its SIMDs finishing together instead of on the few that drew several centre tiles.
+// mode 0: work = list length (ranges), mode 1: work = keys[tile] (forward's per-tile last contributor).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ keys, int mode, int ntiles,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    hist[tid] = 0;
+    uint32_t mx = 0;
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        mx = max(mx, w);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) wmax[wid] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
+    const float scale = mx ? 1023.0f / (float)mx : 0.f;
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
+        atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins
+    const uint32_t v = hist[tid];
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    hist[tid] = woff + x - v;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
+        order[atomicAdd(&hist[bin], 1u)] = (uint32_t)t;
+    }
+}
+
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys, mode,
+                       ntiles, order);
+    GS_LAUNCH_CHECK("tile_order", debug, s);
+    return GS_OK;
+}

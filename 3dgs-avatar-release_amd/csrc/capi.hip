@@ -82,9 +82,10 @@ int gs_binning_bytes(int64_t D, int32_t W, int32_t H, size_t* out) {
     *out = bin_layout(D).total;
     return GS_OK;
 }
-int gs_backward_scratch_bytes(int64_t D, int32_t P, size_t* out) {
-    if (!out || D < 0 || P < 0) return GS_E_BAD_ARG;
-    *out = scratch_total_bytes(D, P);
+int gs_backward_scratch_bytes(int64_t D, int32_t P, int32_t W, int32_t H, size_t* out) {
+    if (!out || D < 0 || P < 0 || W <= 0 || H <= 0) return GS_E_BAD_ARG;
+    const ImgLayout I = img_layout(W, H);
+    *out = scratch_total_bytes(D, P, I.gx * I.gy);
     return GS_OK;
 }
 
@@ -167,9 +168,13 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
     }
+    { StageScope sc_("tile_order", s);
+    rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), a->debug, s); }
+    if (rc != GS_OK) return rc;
     { StageScope sc_("render_fwd", s);
-    rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, a->bg, a->W, a->H, out_color,
-                               (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s); }
+    rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
+                               a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),
+                               (uint32_t*)(im + I.tile_nmax), s); }
     if (rc != GS_OK) return rc;
     if (a->debug) {
         hipError_t e = hipStreamSynchronize(s);
@@ -192,7 +197,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     const ImgLayout I = img_layout(a->W, a->H);
     const BinLayout B = bin_layout(D);
     size_t need = 0;
-    gs_backward_scratch_bytes(D, a->P, &need);
+    gs_backward_scratch_bytes(D, a->P, a->W, a->H, &need);
     if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total) || (a->P > 0 && scratch_bytes < need))
         return GS_E_WORKSPACE;
     if (a->P == 0) return GS_OK;
@@ -204,9 +209,15 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         const int bits = tile_bits(I.gx * I.gy);
         const bool odd = radix_passes(bits) & 1;
         const uint32_t* point_list = (const uint32_t*)(b + (odd ? B.val1 : B.val0));
+        uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_sums_bytes(a->P));
+        { StageScope sc_("tile_order", s);
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), (const uint32_t*)(im + I.tile_nmax), 1, I.gx * I.gy,
+                               order_b, a->debug, s); }
+        if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
-        rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), a->bg, a->W,
-                                    a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix, (float*)scratch, s); }
+        rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), order_b,
+                                    a->bg, a->W, a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix,
+                                    (float*)scratch, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);

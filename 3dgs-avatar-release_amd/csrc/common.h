@@ -66,7 +66,7 @@ static inline BinLayout bin_layout(int64_t D) {
 }
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, total;
+    size_t ranges, n_contrib, final_T, tile_nmax, order, total;
     int gx, gy;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -78,6 +78,8 @@ static inline ImgLayout img_layout(int W, int H) {
     L.ranges = take((size_t)L.gx * L.gy * 8);
     L.n_contrib = take((size_t)W * H * 4);
     L.final_T = take((size_t)W * H * 4);
+    L.tile_nmax = take((size_t)L.gx * L.gy * 4);
+    L.order = take((size_t)L.gx * L.gy * 4);
     L.total = o;
     return L;
 }
@@ -128,18 +130,23 @@ int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint3
                 uint32_t* vals, int P, int gx, int debug, hipStream_t s);
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
 
-int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
-                          int H, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t s);
-int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
-                           int H, const uint32_t* n_contrib, const float* out_color, const float* dL_dpix,
-                           float* entry_grads, hipStream_t s);
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
+                      hipStream_t s);
+int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
+                          const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
+                          uint32_t* tile_nmax, hipStream_t s);
+int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
+                           const float* bg, int W, int H, const uint32_t* n_contrib, const float* out_color,
+                           const float* dL_dpix, float* entry_grads, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const float* entry_grads, float* sums, const GsGrads& g,
                              hipStream_t s);
 // backward scratch: [D rows x 48 B of per-pair gradients | P rows x 48 B of per-Gaussian sums]
 static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * REC_F * 4, 256); }
-static inline size_t scratch_total_bytes(int64_t D, int P) {
-    return scratch_rows_bytes(D) + align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256);
+static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }
+// ... | launch order of the backward tile waves (u32 per tile)]
+static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {
+    return scratch_rows_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);
 }
 
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);

@@ -19,14 +19,15 @@
 
 __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint32_t* __restrict__ point_list,
-                                                        const uint2* __restrict__ ranges, int W, int H, int gx,
+                                                        const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ order, int W, int H, int gx,
                                                         const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ entry_grads) {
     __shared__ float4 srec[64 * 3];
     __shared__ float4 srow[64 * 3];
-    const int tile = blockIdx.x;
+    const int tile = (int)order[blockIdx.x];  // heaviest tiles first (tile_order_kernel on the forward's tile_nmax)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int X0 = tx * TILE, Y0 = ty * TILE;
@@ -95,16 +96,21 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             p1 = rec[(size_t)id * 3 + 1];
             p2 = rec[(size_t)id * 3 + 2];
         }
+        float4 na = srec[0], nb = srec[1], nc = srec[2];  // software-pipelined LDS reads
         for (int j = 0; j < cnt; j++) {
             const uint32_t entry = (uint32_t)(base + j);
-            const float4 b = srec[j * 3 + 1];
+            const float4 a = na, b = nb, c = nc;
+            {
+                const int jn = min(j + 1, 63);
+                na = srec[jn * 3];
+                nb = srec[jn * 3 + 1];
+                nc = srec[jn * 3 + 2];
+            }
             uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w));
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (entry >= qmax[k]) m &= ~(1u << k);
             if (m == 0) continue;
-            const float4 a = srec[j * 3];
-            const float4 c = srec[j * 3 + 2];
             float dx[2], dy[2], ax[2], cy[2], bx[2];
             dx[0] = a.x - pxf;
             dx[1] = dx[0] - 8.f;
@@ -127,30 +133,33 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!(m & (1u << k))) continue;  // wave-uniform
-                if (entry >= ncon[k]) continue;
+                if (!(m & (1u << k))) continue;  // wave-uniform (scalar branch)
                 const float ddx = dx[k & 1], ddy = dy[k >> 1];
                 const float power2 = bx[k & 1] * ddy + (ax[k & 1] + cy[k >> 1]);
-                float alpha, G;
-                if (!splat_alpha2(power2, b.y, b.z, alpha, G)) continue;
-                any = true;
-                const float w = alpha * T[k];
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool valid = (entry < ncon[k]) && (power2 <= 0.0f) && (power2 >= b.z) && (alpha >= (1.0f / 255.0f));
+                if (__ballot(valid) == 0ull) continue;  // wave-uniform
+                any = any || valid;
+                // branch-free from here: invalid lanes carry w = 0, t = 0
+                const float w = valid ? alpha * T[k] : 0.f;
                 const float cg = c.x * g[k][0] + c.y * g[k][1] + c.z * g[k][2];
                 Pfx[k] += cg * w;
-                const float one_m = 1.f - alpha;
+                const float one_m = valid ? 1.f - alpha : 1.f;
                 const float dL_dalpha = T[k] * cg - (Gtot[k] - Pfx[k]) * __builtin_amdgcn_rcpf(one_m);
                 T[k] *= one_m;
                 acc[6] += w * g[k][0];
                 acc[7] += w * g[k][1];
                 acc[8] += w * g[k][2];
-                const float Gd = G * dL_dalpha;
+                const float Gd = valid ? G * dL_dalpha : 0.f;
                 const float t = b.y * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
                 const float u = 2.f * a.z * ddx + a.w * ddy;
                 const float v = 2.f * b.x * ddy + a.w * ddx;
                 acc[0] += t * u;
                 acc[1] += t * v;
-                acc[2] += t * ddx * ddx;
-                acc[3] += t * ddx * ddy;
+                const float tdx = t * ddx;
+                acc[2] += tdx * ddx;
+                acc[3] += tdx * ddy;
                 acc[4] += t * ddy * ddy;
                 acc[5] += Gd;
             }
@@ -187,13 +196,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     }
 }
 
-int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
-                           int H, const uint32_t* n_contrib, const float* out_color, const float* dL_dpix,
-                           float* entry_grads, hipStream_t s) {
+int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
+                           const float* bg, int W, int H, const uint32_t* n_contrib, const float* out_color,
+                           const float* dL_dpix, float* entry_grads, hipStream_t s) {
     (void)bg;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                       point_list, reinterpret_cast<const uint2*>(ranges), W, H, gx, n_contrib, out_color, dL_dpix,
+                       point_list, reinterpret_cast<const uint2*>(ranges), order, W, H, gx, n_contrib, out_color, dL_dpix,
                        reinterpret_cast<float4*>(entry_grads));
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;

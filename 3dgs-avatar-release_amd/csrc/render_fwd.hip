@@ -14,11 +14,14 @@
 
 __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict__ rec,
                                                         const uint32_t* __restrict__ point_list,
-                                                        const uint2* __restrict__ ranges, const float* __restrict__ bg,
-                                                        int W, int H, int gx, float* __restrict__ out_color,
-                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                        const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ order,
+                                                        const float* __restrict__ bg, int W, int H, int gx,
+                                                        float* __restrict__ out_color, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib,
+                                                        uint32_t* __restrict__ tile_nmax) {
     __shared__ float4 srec[64 * 3];
-    const int tile = blockIdx.x;
+    const int tile = (int)order[blockIdx.x];  // heaviest tiles first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int X0 = tx * TILE, Y0 = ty * TILE;
@@ -63,12 +66,17 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             p1 = rec[(size_t)id * 3 + 1];
             p2 = rec[(size_t)id * 3 + 2];
         }
+        float4 na = srec[0], nb = srec[1], nc = srec[2];  // software-pipelined LDS reads
         for (int j = 0; j < cnt; j++) {
-            const float4 b = srec[j * 3 + 1];
+            const float4 a = na, b = nb, c = nc;
+            {
+                const int jn = min(j + 1, 63);
+                na = srec[jn * 3];
+                nb = srec[jn * 3 + 1];
+                nc = srec[jn * 3 + 2];
+            }
             const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w)) & qlive;
             if (m == 0) continue;
-            const float4 a = srec[j * 3];
-            const float4 c = srec[j * 3 + 2];
             const uint32_t contributor = (uint32_t)(base + j + 1);
             float dx[2], dy[2], ax[2], cy[2], bx[2];
             dx[0] = a.x - pxf;
@@ -83,31 +91,35 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!(m & (1u << k))) continue;  // wave-uniform
-                if (!done[k]) {
-                    const float power2 = bx[k & 1] * dy[k >> 1] + (ax[k & 1] + cy[k >> 1]);
-                    float alpha, G;
-                    if (splat_alpha2(power2, b.y, b.z, alpha, G)) {
-                        const float test_T = T[k] * (1.f - alpha);
-                        if (test_T < 0.0001f) {
-                            done[k] = true;
-                        } else {
-                            const float w = alpha * T[k];
-                            C[k][0] += c.x * w;
-                            C[k][1] += c.y * w;
-                            C[k][2] += c.z * w;
-                            T[k] = test_T;
-                            last[k] = contributor;
-                        }
-                    }
+                if (!(m & (1u << k))) continue;  // wave-uniform (scalar branch)
+                // branch-free per-pixel body: everything is computed, then selected
+                const float power2 = bx[k & 1] * dy[k >> 1] + (ax[k & 1] + cy[k >> 1]);
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool valid = !done[k] && (power2 <= 0.0f) && (power2 >= b.z) && (alpha >= (1.0f / 255.0f));
+                const float test_T = T[k] * (1.f - alpha);
+                const bool kill = valid && (test_T < 0.0001f);
+                const bool blend = valid && !kill;
+                const float w = blend ? alpha * T[k] : 0.f;
+                C[k][0] += c.x * w;
+                C[k][1] += c.y * w;
+                C[k][2] += c.z * w;
+                T[k] = blend ? test_T : T[k];
+                last[k] = blend ? contributor : last[k];
+                done[k] = done[k] || kill;
+                if (__ballot(kill) != 0ull) {
+                    if (__ballot(!done[k]) == 0ull) qlive &= ~(1u << k);
                 }
-                if (__ballot(!done[k]) == 0ull) qlive &= ~(1u << k);
             }
             if (qlive == 0) break;
         }
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
+    {
+        const uint32_t nm = wave_max_u32(max(max(last[0], last[1]), max(last[2], last[3])));
+        if (lane == 0) tile_nmax[tile] = nm;  // the backward's work estimate for this tile
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
@@ -122,11 +134,13 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     }
 }
 
-int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const float* bg, int W,
-                          int H, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t s) {
+int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
+                          const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
+                          uint32_t* tile_nmax, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                       point_list, reinterpret_cast<const uint2*>(ranges), bg, W, H, gx, out_color, final_T, n_contrib);
+                       point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx, out_color, final_T,
+                       n_contrib, tile_nmax);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }

@@ -160,7 +160,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                            scales if has_sr else None, rotations if has_sr else None,
                            cov3Ds_precomp if has_cov else None, keep)
             sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            scratch_bytes = _lib.nbytes(L.gs_backward_scratch_bytes, D, P)
+            scratch_bytes = _lib.nbytes(L.gs_backward_scratch_bytes, D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
             M = int(sh.shape[1]) if has_sh else 0
             f = dict(dtype=torch.float32, device=dev)

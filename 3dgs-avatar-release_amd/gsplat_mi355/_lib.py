@@ -50,7 +50,7 @@ def load():
         L.gs_geom_bytes.argtypes = [c_int32, POINTER(c_size_t)]
         L.gs_image_bytes.argtypes = [c_int32, c_int32, POINTER(c_size_t)]
         L.gs_binning_bytes.argtypes = [c_int64, c_int32, c_int32, POINTER(c_size_t)]
-        L.gs_backward_scratch_bytes.argtypes = [c_int64, c_int32, POINTER(c_size_t)]
+        L.gs_backward_scratch_bytes.argtypes = [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]
         L.gs_forward_preprocess.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
                                             c_void_p, c_void_p]
         L.gs_forward_render.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,

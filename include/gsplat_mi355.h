@@ -84,7 +84,7 @@ typedef struct GsGrads {
 int gs_geom_bytes(int32_t P, size_t* out);
 int gs_image_bytes(int32_t W, int32_t H, size_t* out);
 int gs_binning_bytes(int64_t num_rendered, int32_t W, int32_t H, size_t* out);
-int gs_backward_scratch_bytes(int64_t num_rendered, int32_t P, size_t* out);
+int gs_backward_scratch_bytes(int64_t num_rendered, int32_t P, int32_t W, int32_t H, size_t* out);
 
 /* ---- forward, phase 1 (replaces the first half of upstream rasterize_gaussians: preprocess +
  * prefix sum).  Runs: per-Gaussian preprocess (cull, EWA projection, conic, radius, tile rect,
@@ -103,7 +103,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
 
 /* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
  * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `scratch` holds
- * gs_backward_scratch_bytes(num_rendered, P) bytes. */
+ * gs_backward_scratch_bytes(num_rendered, P, W, H) bytes. */
 int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t num_rendered,
                 const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,
