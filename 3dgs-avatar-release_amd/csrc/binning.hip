@@ -181,7 +181,8 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int 
 // resident at once and the hardware deals workgroups breadth-first over the SIMDs, so handing out
 // the tiles heaviest-first gives every SIMD one tile from each work quantile -- the kernel then
 // ends with its SIMDs finishing together instead of on the few that drew several centre tiles.
-// mode 0: work = list length (ranges), mode 1: work = keys[tile] (forward's per-tile last contributor).
+// mode 0: work = list length (ranges), mode 1: work = sum of keys[4 tile .. 4 tile + 3] (the forward's
+// per-quadrant last contributor).
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ keys, int mode, int ntiles,
                                                           uint32_t* __restrict__ order) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     hist[tid] = 0;
     uint32_t mx = 0;
     for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
         mx = max(mx, w);
     }
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
     const float scale = mx ? 1023.0f / (float)mx : 0.f;
     for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
         const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
         atomicAdd(&hist[bin], 1u);
     }
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     hist[tid] = woff + x - v;
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? keys[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
         const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
         order[atomicAdd(&hist[bin], 1u)] = (uint32_t)t;
     }

@@ -55,6 +55,32 @@ __device__ __forceinline__ Staged stage_entry(const float4 r0, const float4 r1, 
     return s;
 }
 
+// The same for ONE 8x8 quadrant with origin (QX0, QY0): returns whether the Gaussian's footprint bbox
+// reaches the quadrant (the forward kernel runs one wave per quadrant and compacts on this flag).
+__device__ __forceinline__ bool stage_entry_quad(const float4 r0, const float4 r1, const float4 r2, int QX0, int QY0,
+                                                 Staged& s) {
+    const float gx = r0.x, gy = r0.y, A = r0.z, B = r0.w, C = r1.x, o = r1.y;
+    const float thr = -__log2f(255.f * o) - 1e-3f;
+    bool hit = false;
+    if (thr <= 0.f) {
+        const float det = A * C - B * B;
+        hit = true;
+        if (det > 0.f) {
+            const float two_tau = (-2.f / LOG2E_F) * thr;
+            const float k = two_tau / det;
+            const float ex = sqrtf(k * C) * 1.0001f + 0.01f;
+            const float ey = sqrtf(k * A) * 1.0001f + 0.01f;
+            const float x0 = gx - ex - (float)QX0, x1 = gx + ex - (float)QX0;
+            const float y0 = gy - ey - (float)QY0, y1 = gy + ey - (float)QY0;
+            hit = (x1 >= 0.f) && (x0 <= 7.f) && (y1 >= 0.f) && (y0 <= 7.f);
+        }
+    }
+    s.a = make_float4(gx, gy, (-0.5f * LOG2E_F) * A, -LOG2E_F * B);
+    s.b = make_float4((-0.5f * LOG2E_F) * C, o, thr, 0.f);
+    s.c = make_float4(r1.z, r1.w, r2.x, 0.f);
+    return hit;
+}
+
 // alpha of one Gaussian at one pixel in the log2 domain.  Rejected if
 // power > 0 or alpha < 1/255.  G = exp(power) is returned for the backward pass.
 __device__ __forceinline__ bool splat_alpha2(float power2, float o, float thr, float& alpha, float& G) {

@@ -216,8 +216,8 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), order_b,
-                                    a->bg, a->W, a->H, (const uint32_t*)(im + I.n_contrib), out_color, dL_dpix,
-                                    (float*)scratch, s); }
+                                    a->bg, a->W, a->H, (const uint32_t*)(im + I.n_contrib),
+                                    (const uint32_t*)(im + I.tile_nmax), out_color, dL_dpix, (float*)scratch, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);

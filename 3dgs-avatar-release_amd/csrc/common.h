@@ -78,7 +78,7 @@ static inline ImgLayout img_layout(int W, int H) {
     L.ranges = take((size_t)L.gx * L.gy * 8);
     L.n_contrib = take((size_t)W * H * 4);
     L.final_T = take((size_t)W * H * 4);
-    L.tile_nmax = take((size_t)L.gx * L.gy * 4);
+    L.tile_nmax = take((size_t)L.gx * L.gy * 16);  // per-quadrant last contributor (4 per tile)
     L.order = take((size_t)L.gx * L.gy * 4);
     L.total = o;
     return L;
@@ -136,8 +136,8 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
                           uint32_t* tile_nmax, hipStream_t s);
 int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
-                           const float* bg, int W, int H, const uint32_t* n_contrib, const float* out_color,
-                           const float* dL_dpix, float* entry_grads, hipStream_t s);
+                           const float* bg, int W, int H, const uint32_t* n_contrib, const uint32_t* quad_nmax,
+                           const float* out_color, const float* dL_dpix, float* entry_grads, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const float* entry_grads, float* sums, const GsGrads& g,
                              hipStream_t s);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order, int W, int H, int gx,
                                                         const uint32_t* __restrict__ n_contrib,
+                                                        const uint32_t* __restrict__ quad_nmax,
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ entry_grads) {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             Gtot[k] = 0.f;
             ncon[k] = 0;
         }
-        qmax[k] = __builtin_amdgcn_readfirstlane(wave_max_u32(ncon[k]));
+        qmax[k] = quad_nmax[tile * 4 + k];  // wave-uniform (scalar load), written by the forward
         nmax_u = max(nmax_u, qmax[k]);
     }
     const int nmax = (int)nmax_u;  // entries >= nmax contribute to no pixel of the tile
@@ -197,12 +198,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 }
 
 int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
-                           const float* bg, int W, int H, const uint32_t* n_contrib, const float* out_color,
-                           const float* dL_dpix, float* entry_grads, hipStream_t s) {
+                           const float* bg, int W, int H, const uint32_t* n_contrib, const uint32_t* quad_nmax,
+                           const float* out_color, const float* dL_dpix, float* entry_grads, hipStream_t s) {
     (void)bg;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                       point_list, reinterpret_cast<const uint2*>(ranges), order, W, H, gx, n_contrib, out_color, dL_dpix,
+                       point_list, reinterpret_cast<const uint2*>(ranges), order, W, H, gx, n_contrib, quad_nmax, out_color,
+                       dL_dpix,
                        reinterpret_cast<float4*>(entry_grads));
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
