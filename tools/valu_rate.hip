@@ -1,0 +1,50 @@
+// Microbenchmark: VALU issue rate on gfx950 (wave64): independent fma chains, dpp adds, exp.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+    float a[8];
+    for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x * 1e-3f;
+    const float m = 1.0001f, c = 0.5f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (MODE == 0) a[i] = __builtin_fmaf(a[i], m, c);
+                if (MODE == 1) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xF, 0xF, false));
+                if (MODE == 2) a[i] = __builtin_amdgcn_exp2f(a[i]) ;
+                if (MODE == 3) a[i] = (a[i] > c) ? a[i] * m : a[i] + c;  // cmp + cndmask-ish
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int MODE>
+void run(const char* name, int blocks_per_cu) {
+    int iters = 4096;
+    int nb = 256 * blocks_per_cu;
+    float* d; hipMalloc(&d, (size_t)nb * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(256), 0, 0, d, 16, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(256), 0, 0, d, iters, 1.0f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double winstr = (double)nb * 4 /*waves*/ * iters * 32.0;  // wave-instructions of the measured op
+    double per_simd = winstr / 1024.0;
+    printf("%-8s blocks/CU=%d  %.3f ms  wave-instr/SIMD=%.3g  ns/instr/SIMD=%.3f  (cycles @2.4GHz: %.2f)\n", name, blocks_per_cu, ms,
+           per_simd, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+    hipFree(d);
+}
+int main() {
+    for (int b : {1, 2, 4, 8}) { run<0>("fma", b); }
+    for (int b : {1, 2, 8}) { run<1>("dpp_add", b); }
+    for (int b : {1, 2, 8}) { run<2>("exp2", b); }
+    for (int b : {1, 2, 8}) { run<3>("cmp_sel", b); }
+    return 0;
+}
