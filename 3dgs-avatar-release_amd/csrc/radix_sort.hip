@@ -1,10 +1,8 @@
 // radix_sort.hip -- stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
 // Replaces the two cub::DeviceRadixSort::SortPairs calls of the upstream path.
 //
-// Per pass: (1) per-block digit histogram, (2) exclusive scan of the digit-major [256][nblk] table,
-// (3) stable scatter.  Stability inside a block comes from processing the block's 4096 keys in 16
-// rounds of 256 (one key per thread, thread order = key order); inside a round each wave64 ranks
-// equal digits with an 8-step ballot match, and the four waves are chained through LDS counters.
+// Per pass: (1) per-block digit histogram (+ global digit totals), (2) exclusive scan of the
+// digit-major [256][nblk] table, one workgroup per digit, (3) stable scatter (see rs_scatter_kernel).
 #include "common.h"
 
 #define RS_THREADS 256
@@ -67,28 +65,55 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
     }
 }
 
+// Stable scatter.  Each wave owns a CONTIGUOUS quarter (1024 keys) of the block's 4096, held in
+// registers (16 per lane, wave-coalesced loads).  Phase 1: wave-private digit histograms in LDS.
+// Phase 2 (one barrier before, one after): turn them into the global start offset of every
+// (wave, digit) = scanned block offset + counts of the waves before.  Phase 3: no further barriers --
+// a wave ranks equal digits inside each 64-key round with an 8-step ballot match and advances its
+// own LDS counters (a wave's LDS operations execute in program order).
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                 int64_t n, int shift, const uint32_t* __restrict__ hist,
                                                                 int nblk) {
-    __shared__ uint32_t gofs[256];     // global base of each digit for this block, advanced per round
-    __shared__ uint32_t wcnt[4][256];  // per-wave digit counts of the current round
+    __shared__ uint32_t whist[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    gofs[tid] = hist[(size_t)tid * nblk + blockIdx.x];
 #pragma unroll
-    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int w = 0; w < 4; w++) whist[w][tid] = 0;
+    const int64_t wbase = (int64_t)blockIdx.x * SORT_ITEMS + wid * (SORT_ITEMS / 4);
+    uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
-        const int64_t i = base + r * RS_THREADS + tid;
-        if (base + r * RS_THREADS >= n) break;  // block-uniform
+        const int64_t i = wbase + r * 64 + lane;
+        key[r] = 0xFFFFFFFFu;
+        val[r] = 0;
+        if (i < n) { key[r] = kin[i]; val[r] = vin[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t i = wbase + r * 64 + lane;
+        if (i < n) atomicAdd(&whist[wid][(key[r] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t run = hist[(size_t)tid * nblk + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = whist[w][tid];
+            whist[w][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        uint32_t key = 0, val = 0;
-        if (valid) { key = kin[i]; val = vin[i]; }
-        const uint32_t digit = (key >> shift) & 255u;
+        const uint32_t digit = (key[r] >> shift) & 255u;
         unsigned long long peers = __ballot(valid);
+        if (peers == 0ull) break;  // wave-uniform: the rest of this wave's chunk lies past n
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const bool bit = (digit >> b) & 1u;
@@ -96,21 +121,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
             peers &= bit ? bal : ~bal;
         }
         const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank == 0) wcnt[wid][digit] = (uint32_t)__popcll(peers);
-        __syncthreads();
+        const uint32_t base = whist[wid][digit];
         if (valid) {
-            uint32_t pos = gofs[digit] + rank;
-            for (int w = 0; w < wid; w++) pos += wcnt[w][digit];
-            kout[pos] = key;
-            vout[pos] = val;
+            kout[base + rank] = key[r];
+            vout[base + rank] = val[r];
+            if (rank == 0) whist[wid][digit] = base + (uint32_t)__popcll(peers);
         }
-        __syncthreads();
-        {
-            const uint32_t add = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-            gofs[tid] += add;
-            wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
-        }
-        __syncthreads();
     }
 }
 

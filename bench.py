@@ -190,6 +190,7 @@ def main():
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {g: round(sum(stage_ms.get(s, 0.0) for s in ss), 4) for g, ss in groups.items()},
+            "stages_detail_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cloud, W, H, deg, gt, do_bwd, args.cpu_threads)
