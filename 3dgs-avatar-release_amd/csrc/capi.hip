@@ -171,10 +171,19 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     { StageScope sc_("tile_order", s);
     rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), a->debug, s); }
     if (rc != GS_OK) return rc;
+    QuadLists ql;
+    ql.kmap = D > 0 ? (uint32_t*)(b + B.kmap) : nullptr;
+    ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
+    ql.ncon_c = (uint32_t*)(im + I.ncon_c);
+    ql.qcount = (uint32_t*)(im + I.tile_nmax);
+    ql.qstaged = (uint32_t*)(im + I.qstaged);
+    if (D > 0) {
+        hipError_t e = hipMemsetAsync(ql.kmap, 0xFF, (size_t)D * 16, s);  // ~0 = "no gradient row for this quadrant"
+        if (e != hipSuccess) { gs_set_error((int)e, "kmap.memset"); return GS_E_HIP; }
+    }
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
-                               a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),
-                               (uint32_t*)(im + I.tile_nmax), s); }
+                               a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
     if (rc != GS_OK) return rc;
     if (a->debug) {
         hipError_t e = hipStreamSynchronize(s);
@@ -206,18 +215,19 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     const char* b = (const char*)binning;
     const char* im = (const char*)img;
     if (D > 0) {
-        const int bits = tile_bits(I.gx * I.gy);
-        const bool odd = radix_passes(bits) & 1;
-        const uint32_t* point_list = (const uint32_t*)(b + (odd ? B.val1 : B.val0));
+        QuadLists ql;
+        ql.kmap = (uint32_t*)(b + B.kmap);
+        ql.qlist = (uint32_t*)(b + B.qlist);
+        ql.ncon_c = (uint32_t*)(im + I.ncon_c);
+        ql.qcount = (uint32_t*)(im + I.tile_nmax);
+        ql.qstaged = (uint32_t*)(im + I.qstaged);
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_sums_bytes(a->P));
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), (const uint32_t*)(im + I.tile_nmax), 1, I.gx * I.gy,
-                               order_b, a->debug, s); }
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
-        rc = launch_render_backward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges), order_b,
-                                    a->bg, a->W, a->H, (const uint32_t*)(im + I.n_contrib),
-                                    (const uint32_t*)(im + I.tile_nmax), out_color, dL_dpix, (float*)scratch, s); }
+        rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
+                                    out_color, dL_dpix, (float*)scratch, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -226,7 +236,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     }
     StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
-                                    (const uint32_t*)(g + L.clamped), (const float*)scratch,
+                                    (const uint32_t*)(g + L.clamped), (const uint32_t*)(b + B.kmap), (const float*)scratch,
                                     (float*)((char*)scratch + scratch_rows_bytes(D)), *gr, s);
 }
 

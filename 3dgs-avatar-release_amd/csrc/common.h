@@ -47,7 +47,7 @@ static inline GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t key0, key1, val0, val1, hist, total;
+    size_t key0, key1, val0, val1, hist, kmap, qlist, total;
     int nblk_sort;
 };
 static inline BinLayout bin_layout(int64_t D) {
@@ -61,12 +61,14 @@ static inline BinLayout bin_layout(int64_t D) {
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
     L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
+    L.kmap = take(n * 16);   // per pair, per quadrant: row of the (quadrant, Gaussian) gradient or ~0
+    L.qlist = take(n * 16);  // per quadrant: compacted Gaussian indices the forward visited
     L.total = o;
     return L;
 }
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, tile_nmax, order, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, qstaged, order, total;
     int gx, gy;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -78,7 +80,9 @@ static inline ImgLayout img_layout(int W, int H) {
     L.ranges = take((size_t)L.gx * L.gy * 8);
     L.n_contrib = take((size_t)W * H * 4);
     L.final_T = take((size_t)W * H * 4);
-    L.tile_nmax = take((size_t)L.gx * L.gy * 16);  // per-quadrant last contributor (4 per tile)
+    L.ncon_c = take((size_t)W * H * 4);            // per pixel: last contributor in its quadrant's COMPACTED list
+    L.tile_nmax = take((size_t)L.gx * L.gy * 16);  // per quadrant: compacted entries up to the last contributor
+    L.qstaged = take((size_t)L.gx * L.gy * 16);    // per quadrant: compacted entries the forward staged
     L.order = take((size_t)L.gx * L.gy * 4);
     L.total = o;
     return L;
@@ -132,17 +136,25 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int 
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
                       hipStream_t s);
+// per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
+struct QuadLists {
+    uint32_t* kmap;     // [D][4]
+    uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
+    uint32_t* ncon_c;   // [H W]
+    uint32_t* qcount;   // [tiles][4]
+    uint32_t* qstaged;  // [tiles][4]
+};
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
-                          uint32_t* tile_nmax, hipStream_t s);
-int launch_render_backward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
-                           const float* bg, int W, int H, const uint32_t* n_contrib, const uint32_t* quad_nmax,
-                           const float* out_color, const float* dL_dpix, float* entry_grads, hipStream_t s);
+                          const QuadLists& ql, hipStream_t s);
+int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
+                           const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
+                           hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const float* entry_grads, float* sums, const GsGrads& g,
-                             hipStream_t s);
-// backward scratch: [D rows x 48 B of per-pair gradients | P rows x 48 B of per-Gaussian sums]
-static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * REC_F * 4, 256); }
+                             const uint32_t* clamped, const uint32_t* kmap, const float* qrows, float* sums,
+                             const GsGrads& g, hipStream_t s);
+// backward scratch: [4 D rows x 48 B of per-(quadrant, Gaussian) gradients | P rows x 48 B of per-Gaussian sums
+static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * REC_F * 4, 256); }
 static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }
 // ... | launch order of the backward tile waves (u32 per tile)]
 static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {

@@ -10,6 +10,11 @@
 // logic at all and reads each staged entry at a wave-uniform address.  The per-pixel body is
 // branch-free (compute, then select).  No barrier spans more than this one wave; the early-out is
 // a wave ballot.
+//
+// The compaction is also RECORDED for the backward pass: qlist (the quadrant's compacted Gaussian
+// indices, in order), kmap (for each (tile, Gaussian) pair and quadrant: where the backward will put
+// that quadrant's gradient row), the per-pixel last contributor in compacted coordinates, and the
+// per-quadrant counts.  The backward therefore never re-derives relevance.
 #include "common.h"
 #include "blend.h"
 
@@ -20,7 +25,9 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
                                                         const float* __restrict__ bg, int W, int H, int gx,
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib,
-                                                        uint32_t* __restrict__ quad_nmax) {
+                                                        uint32_t* __restrict__ kmap, uint32_t* __restrict__ qlist,
+                                                        uint32_t* __restrict__ ncon_c, uint32_t* __restrict__ qcount,
+                                                        uint32_t* __restrict__ qstaged) {
     __shared__ float4 srec[64 * 3];
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel)
     const int q = blockIdx.x & 3;
@@ -32,19 +39,22 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     const bool inside = px < W && py < H;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;  // this quadrant's slice of qlist / gradient rows
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last = 0;
+    uint32_t last = 0, last_k = 0;
+    uint32_t kcount = 0;  // wave-uniform: compacted entries staged so far
     bool done = !inside;
     bool live = __ballot(!done) != 0ull;  // wave-uniform
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    uint32_t pid_g = 0;
     if (live && lane < n) {
-        const uint32_t id = point_list[range.x + lane];
-        p0 = rec[(size_t)id * 3];
-        p1 = rec[(size_t)id * 3 + 1];
-        p2 = rec[(size_t)id * 3 + 2];
+        pid_g = point_list[range.x + lane];
+        p0 = rec[(size_t)pid_g * 3];
+        p1 = rec[(size_t)pid_g * 3 + 1];
+        p2 = rec[(size_t)pid_g * 3 + 2];
     }
     for (int base = 0; base < n && live; base += 64) {
         Staged s;
@@ -54,17 +64,26 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         __syncthreads();
         if (hit) {
             const int slot = __popcll(bal & lt_mask);
+            const uint32_t k = kcount + (uint32_t)slot;  // compacted index of this entry
             s.c.w = __uint_as_float((uint32_t)(base + lane + 1));  // position in the tile's list (1-based)
+            s.b.w = __uint_as_float(k + 1u);
             srec[slot * 3] = s.a;
             srec[slot * 3 + 1] = s.b;
             srec[slot * 3 + 2] = s.c;
+            // record the compaction for the backward
+            const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
+            const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
+            const size_t pair = (size_t)off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx);
+            qlist[qbase + k] = pid_g;
+            kmap[pair * 4 + q] = qbase + k;
         }
         __syncthreads();
+        kcount += (uint32_t)cnt;
         if (base + 64 + lane < n) {
-            const uint32_t id = point_list[range.x + base + 64 + lane];
-            p0 = rec[(size_t)id * 3];
-            p1 = rec[(size_t)id * 3 + 1];
-            p2 = rec[(size_t)id * 3 + 2];
+            pid_g = point_list[range.x + base + 64 + lane];
+            p0 = rec[(size_t)pid_g * 3];
+            p1 = rec[(size_t)pid_g * 3 + 1];
+            p2 = rec[(size_t)pid_g * 3 + 2];
         }
         float4 na = srec[0], nb = srec[1], nc = srec[2];  // software-pipelined LDS reads
         for (int j = 0; j < cnt; j++) {
@@ -89,6 +108,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             C2 += c.z * w;
             T = blend ? test_T : T;
             last = blend ? __float_as_uint(c.w) : last;
+            last_k = blend ? __float_as_uint(b.w) : last_k;
             done = done || kill;
             if (__ballot(kill) != 0ull) {
                 if (__ballot(!done) == 0ull) { live = false; break; }
@@ -96,14 +116,18 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         }
     }
     {
-        const uint32_t nm = wave_max_u32(last);
-        if (lane == 0) quad_nmax[tile * 4 + q] = nm;  // the backward's per-quadrant loop bound / work estimate
+        const uint32_t nm = wave_max_u32(last_k);
+        if (lane == 0) {
+            qcount[tile * 4 + q] = nm;        // the backward's loop bound / work estimate for this quadrant
+            qstaged[tile * 4 + q] = kcount;   // rows [nm, kcount) exist in kmap but receive no gradient
+        }
     }
     if (inside) {
         const size_t HW = (size_t)H * W;
         const size_t pid = (size_t)py * W + px;
         final_T[pid] = T;
         n_contrib[pid] = last;
+        ncon_c[pid] = last_k;
         out_color[pid] = C0 + T * bg[0];
         out_color[HW + pid] = C1 + T * bg[1];
         out_color[2 * HW + pid] = C2 + T * bg[2];
@@ -112,11 +136,11 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
 
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
-                          uint32_t* quad_nmax, hipStream_t s) {
+                          const QuadLists& ql, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                        point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx, out_color, final_T,
-                       n_contrib, quad_nmax);
+                       n_contrib, ql.kmap, ql.qlist, ql.ncon_c, ql.qcount, ql.qstaged);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }
