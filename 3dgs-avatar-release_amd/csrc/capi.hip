@@ -172,15 +172,10 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), a->debug, s); }
     if (rc != GS_OK) return rc;
     QuadLists ql;
-    ql.kmap = D > 0 ? (uint32_t*)(b + B.kmap) : nullptr;
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.qstaged = (uint32_t*)(im + I.qstaged);
-    if (D > 0) {
-        hipError_t e = hipMemsetAsync(ql.kmap, 0xFF, (size_t)D * 16, s);  // ~0 = "no gradient row for this quadrant"
-        if (e != hipSuccess) { gs_set_error((int)e, "kmap.memset"); return GS_E_HIP; }
-    }
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -216,18 +211,22 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     const char* im = (const char*)img;
     if (D > 0) {
         QuadLists ql;
-        ql.kmap = (uint32_t*)(b + B.kmap);
         ql.qlist = (uint32_t*)(b + B.qlist);
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
         ql.qstaged = (uint32_t*)(im + I.qstaged);
-        uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_sums_bytes(a->P));
+        uint8_t* qvalid = (uint8_t*)scratch + scratch_rows_bytes(D);
+        uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
+        {
+            hipError_t e = hipMemsetAsync(qvalid, 0, (size_t)D * 4, s);  // 0 = "row not written"
+            if (e != hipSuccess) { gs_set_error((int)e, "qvalid.memset"); return GS_E_HIP; }
+        }
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
-                                    out_color, dL_dpix, (float*)scratch, s); }
+                                    out_color, dL_dpix, (float*)scratch, qvalid, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -236,8 +235,9 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     }
     StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
-                                    (const uint32_t*)(g + L.clamped), (const uint32_t*)(b + B.kmap), (const float*)scratch,
-                                    (float*)((char*)scratch + scratch_rows_bytes(D)), *gr, s);
+                                    (const uint32_t*)(g + L.clamped), (const uint8_t*)scratch + scratch_rows_bytes(D),
+                                    (const float*)scratch,
+                                    (float*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D)), *gr, s);
 }
 
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -295,6 +295,8 @@ int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
         case 0: *out = m + I.ranges; break;
         case 1: *out = m + I.n_contrib; break;
         case 2: *out = m + I.final_T; break;
+        case 3: *out = m + I.tile_nmax; break;
+        case 4: *out = m + I.ncon_c; break;
         default: return GS_E_BAD_ARG;
     }
     return GS_OK;

@@ -47,7 +47,7 @@ static inline GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t key0, key1, val0, val1, hist, kmap, qlist, total;
+    size_t key0, key1, val0, val1, hist, qlist, total;
     int nblk_sort;
 };
 static inline BinLayout bin_layout(int64_t D) {
@@ -61,7 +61,6 @@ static inline BinLayout bin_layout(int64_t D) {
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
     L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
-    L.kmap = take(n * 16);   // per pair, per quadrant: row of the (quadrant, Gaussian) gradient or ~0
     L.qlist = take(n * 16);  // per quadrant: compacted Gaussian indices the forward visited
     L.total = o;
     return L;
@@ -138,7 +137,6 @@ int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, in
                       hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
-    uint32_t* kmap;     // [D][4]
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
@@ -149,16 +147,17 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
                           const QuadLists& ql, hipStream_t s);
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           hipStream_t s);
+                           uint8_t* qvalid, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const uint32_t* kmap, const float* qrows, float* sums,
+                             const uint32_t* clamped, const uint8_t* qvalid, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s);
-// backward scratch: [4 D rows x 48 B of per-(quadrant, Gaussian) gradients | P rows x 48 B of per-Gaussian sums
+// backward scratch: [4 D rows x 48 B: gradient row of (pair, quadrant) at index 4 pair + quadrant, pairs in
+// emission order | 4 D bytes: row-written flags | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
 static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * REC_F * 4, 256); }
+static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4, 256); }
 static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }
-// ... | launch order of the backward tile waves (u32 per tile)]
 static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {
-    return scratch_rows_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);
+    return scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);
 }
 
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);

@@ -7,14 +7,13 @@
 #include "gs_math.h"
 #include "blend.h"
 
-// Segmented sum of the per-(quadrant, Gaussian) gradient rows: 8 lanes per Gaussian walk its
-// contiguous pair segment; for each pair the forward's kmap names up to four rows (one per 8x8 quadrant
-// the Gaussian reached before the quadrant terminated, ~0 = none); fold with three DPP adds.
-// sums[i] = 12 floats.
+// Segmented sum of the per-(pair, quadrant) gradient rows: 8 lanes per Gaussian walk its contiguous
+// span of pairs; each pair has four row slots (one per 8x8 quadrant of the tile), of which the
+// backward tile kernel wrote those flagged in qvalid; fold with three DPP adds.  sums[i] = 12 floats.
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ tiles,
-                                                             const uint4* __restrict__ kmap,
+                                                             const uint32_t* __restrict__ qvalid,
                                                              const float4* __restrict__ qrows,
                                                              float4* __restrict__ sums) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -27,14 +26,14 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
         const uint32_t tt = tiles[i];
         for (uint32_t k = j; k < tt; k += 8) {
-            const uint4 km = kmap[off + k];
-            const uint32_t r4[4] = {km.x, km.y, km.z, km.w};
+            const uint32_t vm = qvalid[off + k];  // four flag bytes of this pair
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
-                if (r4[qq] == 0xFFFFFFFFu) continue;
-                const float4 e0 = qrows[(size_t)r4[qq] * 3];
-                const float4 e1 = qrows[(size_t)r4[qq] * 3 + 1];
-                const float e2 = qrows[(size_t)r4[qq] * 3 + 2].x;
+                if (!((vm >> (8 * qq)) & 0xFFu)) continue;
+                const size_t row = (size_t)(off + k) * 4 + qq;
+                const float4 e0 = qrows[row * 3];
+                const float4 e1 = qrows[row * 3 + 1];
+                const float e2 = qrows[row * 3 + 2].x;
                 s[0] += e0.x; s[1] += e0.y; s[2] += e0.z; s[3] += e0.w;
                 s[4] += e1.x; s[5] += e1.y; s[6] += e1.z; s[7] += e1.w;
                 s[8] += e2;
@@ -274,11 +273,11 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 }
 
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const uint32_t* kmap, const float* qrows, float* sums,
+                             const uint32_t* clamped, const uint8_t* qvalid, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
     hipLaunchKernelGGL(segment_reduce_kernel, dim3((a.P * 8 + 255) / 256), dim3(256), 0, s, a.P, radii,
-                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint4*>(kmap),
+                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint32_t*>(qvalid),
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
     hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D,

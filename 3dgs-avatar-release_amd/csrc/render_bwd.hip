@@ -8,28 +8,36 @@
 //    64 steps e .. e+63; at step s that lane works on pixel s - e.  A pixel's running state (T, Pfx)
 //    therefore moves one lane per step -- a wave rotate (DPP wave_ror:1) -- and visits the entries
 //    front to back, exactly like the forward.  Each lane keeps its Gaussian's nine gradient sums
-//    in registers over its 64 pixels and stores them once as a plain 48-byte row.  The pipeline is
-//    skewed, so it never drains between chunks of 64 entries: only the first 63 steps of a quadrant
-//    run partly empty.
+//    in registers over its 64 pixels.  The pipeline is skewed, so it never drains between chunks of
+//    64 entries: only the first 63 steps of a quadrant run partly empty.
 //    (The pixel-parallel formulation needs a 64-lane reduction of nine values per list entry; DPP
 //    adds issue at half rate on gfx950 (tools/dpp_rate.hip), which made that reduction ~2/3 of the
 //    kernel.)
-//  * Per-pixel constants (dL/dpixel, Gtot, position, last contributor) sit in LDS and are read at
-//    the lane's current pixel index; entries are staged 64 at a time through a small LDS array, one
-//    chunk ahead, the chunk after that already in flight in registers.
+//  * Entries never touch LDS: every lane gathers the record of its entry of chunk c+2 while chunk
+//    c runs (two register sets), converts it at the round boundary, and at its own switch step
+//    (lane == step mod 64) selects it into the working set.  Per-pixel constants (dL/dpixel, Gtot,
+//    position, last contributor) sit in LDS and are read at the lane's current pixel index, one step
+//    ahead.  A lane that has seen all 64 pixels parks its nine sums in an LDS row; rows go to HBM
+//    64 at a time at the round boundary.
 //  * FRONT-to-back recurrence.  With g = dL/dpixel, Gtot = out_color . g (out_color already holds
 //    T_final * bg) and the running inclusive prefix Pfx_i = sum_{j<=i} (c_j . g) alpha_j T_j,
 //        dL/dalpha_i = T_i (c_i . g) - (Gtot - Pfx_i) / (1 - alpha_i)
 //    which is the reference's back-to-front recurrence (accum_rec / T division) rewritten so that T is
 //    rebuilt by the same multiplications the forward did.
-//  * Output: one row per (quadrant, Gaussian) at qrows[qbase + k], k = compacted index; the forward's
-//    kmap tells the per-Gaussian kernel which rows belong to which (tile, Gaussian) pair.
+//  * Output: the 48-byte gradient row of (pair, quadrant) at qrows[4 pair + quadrant], pairs in EMISSION
+//    order (Gaussian-major), so the per-Gaussian kernel reads one contiguous span per Gaussian; a byte
+//    per row (qvalid, cleared by the caller) says which rows were written.
 #include "common.h"
 #include "blend.h"
 
 __device__ __forceinline__ float wave_ror1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
+
+// the nine per-entry values the inner loop reads
+struct Entry {
+    float x, y, A2, B2, C2, o, r, g, b;
+};
 
 __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint2* __restrict__ ranges,
@@ -37,12 +45,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const uint32_t* __restrict__ qlist,
                                                         const uint32_t* __restrict__ ncon_c,
                                                         const uint32_t* __restrict__ qcount,
-                                                        const uint32_t* __restrict__ qstaged,
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
-                                                        float4* __restrict__ qrows) {
-    __shared__ float4 ring[64 * 3];
-    __shared__ float4 pix[64 * 2];
+                                                        float4* __restrict__ qrows, uint8_t* __restrict__ qvalid) {
+    __shared__ float4 rowbuf[64 * 3];  // finished rows waiting for the bulk store: 9 sums + row index
+    __shared__ float4 pix[64 * 2];     // per-pixel constants
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -53,17 +60,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const int n = (int)(range.y - range.x);
     const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;
     const int m = (int)qcount[tile * 4 + q];
-    const int staged = (int)qstaged[tile * 4 + q];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // rows the forward announced in kmap but that lie past the quadrant's last contributor
-    for (int k = m + lane; k < staged; k += 64) {
-        qrows[(size_t)(qbase + k) * 3] = zero4;
-        qrows[(size_t)(qbase + k) * 3 + 1] = zero4;
-        qrows[(size_t)(qbase + k) * 3 + 2] = zero4;
-    }
     if (m == 0) return;
-
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         float4 c0 = zero4, c1 = make_float4((float)px, (float)py, 0.f, 0.f);
         if (px < W && py < H) {
@@ -77,94 +75,117 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         pix[lane * 2 + 1] = c1;
     }
 
-    // chunk 0 -> LDS now, chunk 1 -> registers (in flight during round 0)
+    // record (p0,p1,p2) -> the loop's entry form + the row index 4 pair + quadrant
+    auto convert = [&](const float4 p0, const float4 p1, const float4 p2, Entry& e, uint32_t& row) {
+        e.x = p0.x; e.y = p0.y;
+        e.A2 = (-0.5f * LOG2E_F) * p0.z;
+        e.B2 = -LOG2E_F * p0.w;
+        e.C2 = (-0.5f * LOG2E_F) * p1.x;
+        e.o = p1.y; e.r = p1.z; e.g = p1.w; e.b = p2.x;
+        const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
+        const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
+        row = (off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx)) * 4u + (uint32_t)q;
+    };
+    auto gather = [&](int k, float4& p0, float4& p1, float4& p2) {
+        if (k < m) {
+            const uint32_t id = qlist[qbase + k];
+            p0 = rec[(size_t)id * 3];
+            p1 = rec[(size_t)id * 3 + 1];
+            p2 = rec[(size_t)id * 3 + 2];
+        }
+    };
+
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
-    if (lane < m) {
-        const uint32_t id = qlist[qbase + lane];
-        p0 = rec[(size_t)id * 3];
-        p1 = rec[(size_t)id * 3 + 1];
-        p2 = rec[(size_t)id * 3 + 2];
-    }
-    {
-        Staged s;
-        stage_entry_quad(p0, p1, p2, QX0, QY0, s);
-        ring[lane * 3] = s.a;
-        ring[lane * 3 + 1] = s.b;
-        ring[lane * 3 + 2] = s.c;
-    }
-    if (64 + lane < m) {
-        const uint32_t id = qlist[qbase + 64 + lane];
-        p0 = rec[(size_t)id * 3];
-        p1 = rec[(size_t)id * 3 + 1];
-        p2 = rec[(size_t)id * 3 + 2];
-    }
+    Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
+    uint32_t cur_row = 0, nxt_row = 0;  // row index of the lane's working entry / of its entry in `nxt`
+    gather(lane, p0, p1, p2);
+    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by lane t at step t
+    gather(64 + lane, p0, p1, p2);      // chunk 1 in flight during round 0
     __syncthreads();
 
-    float4 ca = zero4, cb = zero4, cc = zero4;  // this lane's current entry
-    bool has = false;
-    uint32_t myk = 0;
+    bool has = false;   // the lane holds a live entry
+    bool pend = false;  // rowbuf[lane] holds a row not yet stored
     float acc[9];
 #pragma unroll
     for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
-    float T = 1.0f, Pfx = 0.f;       // state of the pixel currently at this lane
-    int pidx = (64 - lane) & 63;     // index of that pixel: (s - lane) mod 64
+    float T = 1.0f, Pfx = 0.f;    // state of the pixel currently at this lane
+    int pidx = (64 - lane) & 63;  // index of that pixel: (s - lane) mod 64
+    float4 pc0 = pix[pidx * 2], pc1 = pix[pidx * 2 + 1];
     const float il2 = 1.0f / LOG2E_F;
+
+    auto store_pending = [&]() {
+        if (pend) {
+            const float4 r0 = rowbuf[lane * 3], r1 = rowbuf[lane * 3 + 1], r2 = rowbuf[lane * 3 + 2];
+            const size_t row = __float_as_uint(r2.y);
+            qrows[row * 3] = make_float4(r0.x * il2, r0.y * il2, -0.5f * r0.z, -0.5f * r0.w);
+            qrows[row * 3 + 1] = make_float4(-0.5f * r1.x, r1.y, r1.z, r1.w);
+            qrows[row * 3 + 2] = make_float4(r2.x, 0.f, 0.f, 0.f);
+            qvalid[row] = 1;
+            pend = false;
+        }
+    };
 
     const int total = m + 63;
     for (int s = 0; s < total; s++) {
         const int t = s & 63;
         if (t == 0 && s > 0) {
-            // round start: chunk s/64 (prefetched) -> LDS; chunk s/64 + 1 -> registers.  All lanes
-            // finished reading the previous chunk from LDS during the previous round.
+            // round start: every lane took its entry of the previous chunk out of `nxt` during the
+            // previous round.  Rows finished during that round -> HBM; the chunk that was in flight ->
+            // `nxt`; the chunk after it -> in flight.
             __syncthreads();
-            Staged sg;
-            stage_entry_quad(p0, p1, p2, QX0, QY0, sg);
-            ring[lane * 3] = sg.a;
-            ring[lane * 3 + 1] = sg.b;
-            ring[lane * 3 + 2] = sg.c;
-            if (s + 64 + lane < m) {
-                const uint32_t id = qlist[qbase + s + 64 + lane];
-                p0 = rec[(size_t)id * 3];
-                p1 = rec[(size_t)id * 3 + 1];
-                p2 = rec[(size_t)id * 3 + 2];
-            }
+            store_pending();
+            convert(p0, p1, p2, nxt, nxt_row);
+            gather(s + 64 + lane, p0, p1, p2);
             __syncthreads();
         }
-        if (lane == t) {
-            // this lane has seen all 64 pixels with its entry: store the row, take the next entry
-            if (has) {
-                const size_t row = (size_t)(qbase + myk) * 3;
-                qrows[row] = make_float4(acc[0] * il2, acc[1] * il2, -0.5f * acc[2], -0.5f * acc[3]);
-                qrows[row + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
-                qrows[row + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
-            }
-            has = s < m;
-            myk = (uint32_t)s;
-            ca = ring[t * 3];
-            cb = ring[t * 3 + 1];
-            cc = ring[t * 3 + 2];
+        const bool sw = lane == t;
+        if (sw && has) {
+            // this lane has seen all 64 pixels with its entry: park the row
+            rowbuf[t * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            rowbuf[t * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            rowbuf[t * 3 + 2] = make_float4(acc[8], __uint_as_float(cur_row), 0.f, 0.f);
+            pend = true;
+        }
+        // ... and take the next entry (selects, no divergent block)
+        has = sw ? (s < m) : has;
+        cur.x = sw ? nxt.x : cur.x;
+        cur.y = sw ? nxt.y : cur.y;
+        cur.A2 = sw ? nxt.A2 : cur.A2;
+        cur.B2 = sw ? nxt.B2 : cur.B2;
+        cur.C2 = sw ? nxt.C2 : cur.C2;
+        cur.o = sw ? nxt.o : cur.o;
+        cur.r = sw ? nxt.r : cur.r;
+        cur.g = sw ? nxt.g : cur.g;
+        cur.b = sw ? nxt.b : cur.b;
+        cur_row = sw ? nxt_row : cur_row;
 #pragma unroll
-            for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
-        }
+        for (int c9 = 0; c9 < 9; c9++) acc[c9] = sw ? 0.f : acc[c9];
         {
-            const float4 pc0 = pix[pidx * 2], pc1 = pix[pidx * 2 + 1];
-            const float dx = ca.x - pc1.x, dy = ca.y - pc1.y;
-            const float power2 = ca.z * dx * dx + (cb.x * dy * dy + ca.w * dx * dy);
+            const float4 g = pc0;  // (g0, g1, g2, Gtot) of the pixel at this lane
+            const float pxf = pc1.x, pyf = pc1.y;
+            const uint32_t ncon = __float_as_uint(pc1.z);
+            const uint32_t k = (uint32_t)(s - pidx);  // compacted index of this lane's entry (pidx = s - k)
+            // next step's pixel constants, fetched now
+            pidx = (pidx + 1) & 63;
+            pc0 = pix[pidx * 2];
+            pc1 = pix[pidx * 2 + 1];
+            const float dx = cur.x - pxf, dy = cur.y - pyf;
+            const float power2 = cur.A2 * dx * dx + (cur.C2 * dy * dy + cur.B2 * dx * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
-            const float alpha = fminf(0.99f, cb.y * G);
-            const bool valid = has && (myk < __float_as_uint(pc1.z)) && (power2 <= 0.0f) && (power2 >= cb.z) &&
-                               (alpha >= (1.0f / 255.0f));
+            const float alpha = fminf(0.99f, cur.o * G);
+            // (the forward's relaxed power2 >= thr pre-test is implied by alpha >= 1/255)
+            const bool valid = has && (k < ncon) && (power2 <= 0.0f) && (alpha >= (1.0f / 255.0f));
             // branch-free: invalid lanes carry wgt = 0, t = 0 and leave the pixel state untouched
             const float wgt = valid ? alpha * T : 0.f;
-            const float cg = cc.x * pc0.x + cc.y * pc0.y + cc.z * pc0.z;
+            const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
             Pfx += cg * wgt;
             const float one_m = valid ? 1.f - alpha : 1.f;
-            const float dL_dalpha = T * cg - (pc0.w - Pfx) * __builtin_amdgcn_rcpf(one_m);
+            const float dL_dalpha = T * cg - (g.w - Pfx) * __builtin_amdgcn_rcpf(one_m);
             T *= one_m;
             const float Gd = valid ? G * dL_dalpha : 0.f;
-            const float tt = cb.y * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
-            const float u = 2.f * ca.z * dx + ca.w * dy;
-            const float v = 2.f * cb.x * dy + ca.w * dx;
+            const float tt = cur.o * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
+            const float u = 2.f * cur.A2 * dx + cur.B2 * dy;
+            const float v = 2.f * cur.C2 * dy + cur.B2 * dx;
             const float tdx = tt * dx;
             // sums (constant factors applied when the row is stored):
             //  0: t*u -> dL/dmean.x * log2e   1: t*v   2: t dx^2  3: t dx dy  4: t dy^2 (-> -2 dL/dconic)
@@ -175,30 +196,32 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             acc[3] += tdx * dy;
             acc[4] += tt * dy * dy;
             acc[5] += Gd;
-            acc[6] += wgt * pc0.x;
-            acc[7] += wgt * pc0.y;
-            acc[8] += wgt * pc0.z;
+            acc[6] += wgt * g.x;
+            acc[7] += wgt * g.y;
+            acc[8] += wgt * g.z;
         }
         // the pixel moves on to the next entry = the next lane
         T = wave_ror1(T);
         Pfx = wave_ror1(Pfx);
-        pidx = (pidx + 1) & 63;
     }
+    __syncthreads();
+    store_pending();
     if (has) {
-        const size_t row = (size_t)(qbase + myk) * 3;
-        qrows[row] = make_float4(acc[0] * il2, acc[1] * il2, -0.5f * acc[2], -0.5f * acc[3]);
-        qrows[row + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
-        qrows[row + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+        const size_t row = cur_row;
+        qrows[row * 3] = make_float4(acc[0] * il2, acc[1] * il2, -0.5f * acc[2], -0.5f * acc[3]);
+        qrows[row * 3 + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
+        qrows[row * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+        qvalid[row] = 1;
     }
 }
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           hipStream_t s) {
+                           uint8_t* qvalid, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                        reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
-                       ql.qstaged, out_color, dL_dpix, reinterpret_cast<float4*>(qrows));
+                       out_color, dL_dpix, reinterpret_cast<float4*>(qrows), qvalid);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

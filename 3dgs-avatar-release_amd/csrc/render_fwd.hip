@@ -12,9 +12,8 @@
 // a wave ballot.
 //
 // The compaction is also RECORDED for the backward pass: qlist (the quadrant's compacted Gaussian
-// indices, in order), kmap (for each (tile, Gaussian) pair and quadrant: where the backward will put
-// that quadrant's gradient row), the per-pixel last contributor in compacted coordinates, and the
-// per-quadrant counts.  The backward therefore never re-derives relevance.
+// indices, in order), the per-pixel last contributor in compacted coordinates, and the per-quadrant
+// count up to the last contributor.  The backward therefore never re-derives relevance.
 #include "common.h"
 #include "blend.h"
 
@@ -25,9 +24,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
                                                         const float* __restrict__ bg, int W, int H, int gx,
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib,
-                                                        uint32_t* __restrict__ kmap, uint32_t* __restrict__ qlist,
-                                                        uint32_t* __restrict__ ncon_c, uint32_t* __restrict__ qcount,
-                                                        uint32_t* __restrict__ qstaged) {
+                                                        uint32_t* __restrict__ qlist, uint32_t* __restrict__ ncon_c,
+                                                        uint32_t* __restrict__ qcount) {
     __shared__ float4 srec[64 * 3];
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel)
     const int q = blockIdx.x & 3;
@@ -70,12 +68,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             srec[slot * 3] = s.a;
             srec[slot * 3 + 1] = s.b;
             srec[slot * 3 + 2] = s.c;
-            // record the compaction for the backward
-            const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
-            const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
-            const size_t pair = (size_t)off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx);
-            qlist[qbase + k] = pid_g;
-            kmap[pair * 4 + q] = qbase + k;
+            qlist[qbase + k] = pid_g;  // record the compaction for the backward
         }
         __syncthreads();
         kcount += (uint32_t)cnt;
@@ -117,10 +110,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     }
     {
         const uint32_t nm = wave_max_u32(last_k);
-        if (lane == 0) {
-            qcount[tile * 4 + q] = nm;        // the backward's loop bound / work estimate for this quadrant
-            qstaged[tile * 4 + q] = kcount;   // rows [nm, kcount) exist in kmap but receive no gradient
-        }
+        if (lane == 0) qcount[tile * 4 + q] = nm;  // the backward's loop bound / work estimate for this quadrant
     }
     if (inside) {
         const size_t HW = (size_t)H * W;
@@ -140,7 +130,7 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                        point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx, out_color, final_T,
-                       n_contrib, ql.kmap, ql.qlist, ql.ncon_c, ql.qcount, ql.qstaged);
+                       n_contrib, ql.qlist, ql.ncon_c, ql.qcount);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }

@@ -69,6 +69,7 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
             ranges=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 0), 8 * gx * gy, np.uint32).reshape(-1, 2),
             n_contrib=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 1), 4 * W * H, np.uint32).reshape(H, W),
             final_T=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 2), 4 * W * H, np.float32).reshape(H, W),
+            qcount=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 3), 16 * gx * gy, np.uint32).reshape(-1, 4),
         )
     return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im)
 

@@ -123,7 +123,9 @@ int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, s
  *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))
  *           3 clamped bitmask u32[P]   4 depth-sorted Gaussian index u32[P]   5 num_rendered u64[1]
  *  binning: 0 point_list u32[D] (sorted (tile, depth) order)   1 sorted tile ids u32[D]
- *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W] */
+ *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W]
+ *           3 per-quadrant compacted count up to the last contributor u32[tiles,4]
+ *           4 per-pixel last contributor in compacted coordinates u32[H,W] */
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
 int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);

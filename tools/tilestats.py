@@ -19,3 +19,5 @@ print("processed (max n_contrib per tile): mean %.0f max %d p90 %d" % (ncmax.mea
 print("sum processed / sum len = %.3f" % (ncmax.sum()/ln.sum()))
 print("radii mean %.1f max %d; tiles_touched mean %.1f" % (st["radii"].mean(), st["radii"].max(), st["geom"]["tiles_touched"].mean()))
 rec = st["geom"]["rec"]; print("opacity mean %.3f median %.3f frac<1/255 %.4f" % (rec[:,5].mean(), np.median(rec[:,5]), (rec[:,5]<1/255).mean()))
+qc = st["image"]["qcount"].astype(np.int64)
+print("compacted entries up to last contributor: sum %d (%.3f D), per quadrant mean %.0f max %d; steps incl. fill %d" % (qc.sum(), qc.sum()/st["D"], qc.mean(), qc.max(), (qc + 63 * (qc > 0)).sum()))
