@@ -55,24 +55,35 @@ __device__ __forceinline__ Staged stage_entry(const float4 r0, const float4 r1, 
     return s;
 }
 
-// The same for ONE 8x8 quadrant with origin (QX0, QY0): returns whether the Gaussian's footprint bbox
-// reaches the quadrant (the forward kernel runs one wave per quadrant and compacts on this flag).
+// The same for ONE 8x8 quadrant with origin (QX0, QY0): returns whether the Gaussian can reach the
+// quadrant at all (the forward kernel runs one wave per quadrant and compacts on this flag).
+// EXACT ellipse-vs-rectangle test: the minimum over the quadrant's pixel-centre rectangle of the
+// quadratic form q(d) = A dx^2 + 2 B dx dy + C dy^2 (convex, so either the centre lies inside, or the
+// minimum sits on one of the four edges, where it is a clamped 1-D parabola) against
+// 2 tau = 2 ln(255 opacity) (+ slack).  alpha >= 1/255 <=> q <= 2 ln(255 opacity); the test keeps a
+// 1e-3 (log2) slack plus a relative 1e-4, so every pair it drops would fail the per-pixel alpha test.
+__device__ __forceinline__ float edge_min(float a, float b2, float c, float xf, float y0, float y1) {
+    // min over y in [y0, y1] of a xf^2 + b2 xf y + c y^2   (b2 = 2 B)
+    const float ys = fminf(fmaxf(-0.5f * b2 * xf / c, y0), y1);
+    return a * xf * xf + (b2 * xf + c * ys) * ys;
+}
 __device__ __forceinline__ bool stage_entry_quad(const float4 r0, const float4 r1, const float4 r2, int QX0, int QY0,
                                                  Staged& s) {
     const float gx = r0.x, gy = r0.y, A = r0.z, B = r0.w, C = r1.x, o = r1.y;
     const float thr = -__log2f(255.f * o) - 1e-3f;
     bool hit = false;
     if (thr <= 0.f) {
-        const float det = A * C - B * B;
         hit = true;
-        if (det > 0.f) {
+        if (A > 0.f && C > 0.f) {
             const float two_tau = (-2.f / LOG2E_F) * thr;
-            const float k = two_tau / det;
-            const float ex = sqrtf(k * C) * 1.0001f + 0.01f;
-            const float ey = sqrtf(k * A) * 1.0001f + 0.01f;
-            const float x0 = gx - ex - (float)QX0, x1 = gx + ex - (float)QX0;
-            const float y0 = gy - ey - (float)QY0, y1 = gy + ey - (float)QY0;
-            hit = (x1 >= 0.f) && (x0 <= 7.f) && (y1 >= 0.f) && (y0 <= 7.f);
+            // rectangle of pixel centres relative to the Gaussian centre
+            const float x0 = (float)QX0 - gx, x1 = x0 + 7.f;
+            const float y0 = (float)QY0 - gy, y1 = y0 + 7.f;
+            const bool inside = (x0 <= 0.f) && (x1 >= 0.f) && (y0 <= 0.f) && (y1 >= 0.f);
+            const float b2 = 2.f * B;
+            const float qmin = fminf(fminf(edge_min(A, b2, C, x0, y0, y1), edge_min(A, b2, C, x1, y0, y1)),
+                                     fminf(edge_min(C, b2, A, y0, x0, x1), edge_min(C, b2, A, y1, x0, x1)));
+            hit = inside || (qmin * 0.9999f - 1e-3f <= two_tau);
         }
     }
     s.a = make_float4(gx, gy, (-0.5f * LOG2E_F) * A, -LOG2E_F * B);
