@@ -7,9 +7,9 @@
 #include "gs_math.h"
 #include "blend.h"
 
-// Segmented sum of the per-(pair, quadrant) gradient rows: 8 lanes per Gaussian walk its contiguous
+// Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous
 // span of pairs; each pair has four row slots (one per 8x8 quadrant of the tile), of which the
-// backward tile kernel wrote those flagged in qvalid; fold with three DPP adds.  sums[i] = 12 floats.
+// backward tile kernel wrote those flagged in qvalid; fold with four DPP adds.  sums[i] = 12 floats.
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ tiles,
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
                                                              const float4* __restrict__ qrows,
                                                              float4* __restrict__ sums) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = t >> 3, j = t & 7;
+    const int i = t >> 4, j = t & 15;
     float s[9];
 #pragma unroll
     for (int c = 0; c < 9; c++) s[c] = 0.f;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
     if (in && radii[i] > 0) {
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
         const uint32_t tt = tiles[i];
-        for (uint32_t k = j; k < tt; k += 8) {
+        for (uint32_t k = j; k < tt; k += 16) {
             const uint32_t vm = qvalid[off + k];  // four flag bytes of this pair
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
         v += dpp_get<0xB1, 0xF>(v);   // lane ^ 1
         v += dpp_get<0x4E, 0xF>(v);   // lane ^ 2
         v += dpp_get<0x141, 0xF>(v);  // row_half_mirror: lane <-> 7 - lane inside each group of 8
+        v += dpp_get<0x140, 0xF>(v);  // row_mirror: lane <-> 15 - lane inside the row of 16
         s[c] = v;
     }
     if (in && j < 3) {
@@ -276,7 +277,7 @@ int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const flo
                              const uint32_t* clamped, const uint8_t* qvalid, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
-    hipLaunchKernelGGL(segment_reduce_kernel, dim3((a.P * 8 + 255) / 256), dim3(256), 0, s, a.P, radii,
+    hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)(((size_t)a.P * 16 + 255) / 256)), dim3(256), 0, s, a.P, radii,
                        reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint32_t*>(qvalid),
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);

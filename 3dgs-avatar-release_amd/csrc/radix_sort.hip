@@ -67,20 +67,28 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
 
 // Stable scatter.  Each wave owns a CONTIGUOUS quarter (1024 keys) of the block's 4096, held in
 // registers (16 per lane, wave-coalesced loads).  Phase 1: wave-private digit histograms in LDS.
-// Phase 2 (one barrier before, one after): turn them into the global start offset of every
-// (wave, digit) = scanned block offset + counts of the waves before.  Phase 3: no further barriers --
-// a wave ranks equal digits inside each 64-key round with an 8-step ballot match and advances its
-// own LDS counters (a wave's LDS operations execute in program order).
+// Phase 2: a 256-wide exclusive scan turns them into BLOCK-LOCAL start offsets of every (wave, digit)
+// and a per-digit delta = global start - local start.  Phase 3: each wave ranks equal digits inside
+// each 64-key round with an 8-step ballot match, advances its own LDS counters (a wave's LDS
+// operations execute in program order) and parks the pairs in LDS in block-sorted order.  Phase 4:
+// the block writes the parked pairs out linearly, so every digit's run leaves as one contiguous,
+// coalesced burst (position = local index + delta[digit]).
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                 int64_t n, int shift, const uint32_t* __restrict__ hist,
                                                                 int nblk) {
     __shared__ uint32_t whist[4][256];
+    __shared__ uint32_t delta[256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t skey[SORT_ITEMS];
+    __shared__ uint32_t sval[SORT_ITEMS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) whist[w][tid] = 0;
-    const int64_t wbase = (int64_t)blockIdx.x * SORT_ITEMS + wid * (SORT_ITEMS / 4);
+    const int64_t bbase = (int64_t)blockIdx.x * SORT_ITEMS;
+    const int64_t wbase = bbase + wid * (SORT_ITEMS / 4);
+    const int nvalid = (int)((n - bbase) < (int64_t)SORT_ITEMS ? (n - bbase) : (int64_t)SORT_ITEMS);
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
@@ -97,13 +105,25 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
     {
-        uint32_t run = hist[(size_t)tid * nblk + blockIdx.x];
+        // thread d: counts of digit d per wave -> block-exclusive scan over digits
+        const uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t x = tot;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const uint32_t c = whist[w][tid];
-            whist[w][tid] = run;
-            run += c;
+        for (int k = 1; k < 64; k <<= 1) {
+            uint32_t y = __shfl_up(x, k, 64);
+            if (lane >= k) x += y;
         }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wsum[w];
+        const uint32_t lstart = woff + x - tot;
+        whist[0][tid] = lstart;
+        whist[1][tid] = lstart + c0;
+        whist[2][tid] = lstart + c0 + c1;
+        whist[3][tid] = lstart + c0 + c1 + c2;
+        delta[tid] = hist[(size_t)tid * nblk + blockIdx.x] - lstart;
     }
     __syncthreads();
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -123,9 +143,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
         const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
         const uint32_t base = whist[wid][digit];
         if (valid) {
-            kout[base + rank] = key[r];
-            vout[base + rank] = val[r];
+            skey[base + rank] = key[r];
+            sval[base + rank] = val[r];
             if (rank == 0) whist[wid][digit] = base + (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int i = r * RS_THREADS + tid;
+        if (i < nvalid) {
+            const uint32_t k = skey[i];
+            const uint32_t pos = (uint32_t)i + delta[(k >> shift) & 255u];
+            kout[pos] = k;
+            vout[pos] = sval[i];
         }
     }
 }
