@@ -8,18 +8,38 @@
 #define RS_THREADS 256
 #define RS_ROUNDS (SORT_ITEMS / RS_THREADS)
 
+// wave-level digit match: lanes holding the same 8-bit digit find each other with 8 ballots.
+// Returns the peer mask (lanes with my digit among the `valid` ones).
+__device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (digit >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+// Per-block digit histogram.  Equal digits inside a wave are matched first and counted by one lane,
+// so runs of identical keys (tile ids in emission order, depth exponents) do not serialise on one
+// LDS address.
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                              uint32_t* __restrict__ hist, int nblk,
                                                              uint32_t* __restrict__ totals) {
     __shared__ uint32_t h[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     h[tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll 4
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = base + r * RS_THREADS + tid;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        const bool valid = i < n;
+        const uint32_t digit = valid ? ((keys[i] >> shift) & 255u) : 0u;
+        const unsigned long long peers = match_digit(digit, valid);
+        if (valid && (peers & lt_mask) == 0ull) atomicAdd(&h[digit], (uint32_t)__popcll(peers));
     }
     __syncthreads();
     hist[(size_t)tid * nblk + blockIdx.x] = h[tid];
@@ -66,11 +86,11 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
 }
 
 // Stable scatter.  Each wave owns a CONTIGUOUS quarter (1024 keys) of the block's 4096, held in
-// registers (16 per lane, wave-coalesced loads).  Phase 1: wave-private digit histograms in LDS.
+// registers (16 per lane, wave-coalesced loads).  Phase 1: one ballot-match pass gives every key its
+// rank among the equal digits of its wave's chunk and leaves the wave-private digit counts in LDS.
 // Phase 2: a 256-wide exclusive scan turns them into BLOCK-LOCAL start offsets of every (wave, digit)
-// and a per-digit delta = global start - local start.  Phase 3: each wave ranks equal digits inside
-// each 64-key round with an 8-step ballot match, advances its own LDS counters (a wave's LDS
-// operations execute in program order) and parks the pairs in LDS in block-sorted order.  Phase 4:
+// and a per-digit delta = global start - local start.  Phase 3: the pairs are parked in LDS in
+// block-sorted order (start offset + rank).  Phase 4:
 // the block writes the parked pairs out linearly, so every digit's run leaves as one contiguous,
 // coalesced burst (position = local index + delta[digit]).
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
@@ -98,10 +118,21 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
         if (i < n) { key[r] = kin[i]; val[r] = vin[i]; }
     }
     __syncthreads();
+    // one match pass: rank of every key among the equal digits of its wave's chunk (earlier rounds +
+    // lower lanes).  Only this wave touches whist[wid], and a wave's LDS operations execute in
+    // program order, so plain read / leader write replaces atomics.
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t lrank[RS_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = wbase + r * 64 + lane;
-        if (i < n) atomicAdd(&whist[wid][(key[r] >> shift) & 255u], 1u);
+        const bool valid = i < n;
+        const uint32_t digit = (key[r] >> shift) & 255u;
+        const unsigned long long peers = match_digit(digit, valid);
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t seen = whist[wid][digit];
+        lrank[r] = seen + rank;
+        if (valid && rank == 0) whist[wid][digit] = seen + (uint32_t)__popcll(peers);
     }
     __syncthreads();
     {
@@ -126,26 +157,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
         delta[tid] = hist[(size_t)tid * nblk + blockIdx.x] - lstart;
     }
     __syncthreads();
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = wbase + r * 64 + lane;
-        const bool valid = i < n;
-        const uint32_t digit = (key[r] >> shift) & 255u;
-        unsigned long long peers = __ballot(valid);
-        if (peers == 0ull) break;  // wave-uniform: the rest of this wave's chunk lies past n
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (digit >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        const uint32_t base = whist[wid][digit];
-        if (valid) {
-            skey[base + rank] = key[r];
-            sval[base + rank] = val[r];
-            if (rank == 0) whist[wid][digit] = base + (uint32_t)__popcll(peers);
+        if (i < n) {
+            const uint32_t lpos = whist[wid][(key[r] >> shift) & 255u] + lrank[r];
+            skey[lpos] = key[r];
+            sval[lpos] = val[r];
         }
     }
     __syncthreads();

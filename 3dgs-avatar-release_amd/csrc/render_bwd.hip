@@ -172,17 +172,21 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float dx = cur.x - pxf, dy = cur.y - pyf;
             const float power2 = cur.A2 * dx * dx + (cur.C2 * dy * dy + cur.B2 * dx * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
-            const float alpha = fminf(0.99f, cur.o * G);
-            // (the forward's relaxed power2 >= thr pre-test is implied by alpha >= 1/255)
-            const bool valid = has && (k < ncon) && (power2 <= 0.0f) && (alpha >= (1.0f / 255.0f));
-            // branch-free: invalid lanes carry wgt = 0, t = 0 and leave the pixel state untouched
-            const float wgt = valid ? alpha * T : 0.f;
+            const float al = fminf(0.99f, cur.o * G);
+            // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
+            // power <= 0, the entry lies before the pixel's last contributor (k < ncon; also false for
+            // lanes without an entry: their k is out of range), and alpha >= 1/255 (which implies the
+            // forward's relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
+            const float a1 = (power2 <= 0.0f) ? al : 0.f;
+            const float a2 = (k < ncon) ? a1 : 0.f;
+            const float alpha = (a2 >= (1.0f / 255.0f)) ? a2 : 0.f;
+            const float wgt = alpha * T;
             const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
             Pfx += cg * wgt;
-            const float one_m = valid ? 1.f - alpha : 1.f;
+            const float one_m = 1.f - alpha;
             const float dL_dalpha = T * cg - (g.w - Pfx) * __builtin_amdgcn_rcpf(one_m);
             T *= one_m;
-            const float Gd = valid ? G * dL_dalpha : 0.f;
+            const float Gd = (alpha > 0.f) ? G * dL_dalpha : 0.f;
             const float tt = cur.o * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
             const float u = 2.f * cur.A2 * dx + cur.B2 * dy;
             const float v = 2.f * cur.C2 * dy + cur.B2 * dx;

@@ -40,11 +40,15 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;  // this quadrant's slice of qlist / gradient rows
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    // A pixel is "alive" while T > 0.  The sign of T doubles as the done flag: when a contribution
+    // would push T below 1e-4 the pixel is frozen as T := -T, which keeps final_T and makes every later
+    // test fail by itself.  All per-pixel decisions are VALU compares + selects (v_cmp -> vcc ->
+    // v_cndmask): no scalar mask arithmetic in the inner loop -- the CU's single scalar unit was the
+    // bottleneck of the mask-based version.
+    float T = inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;  // wave-uniform: compacted entries staged so far
-    bool done = !inside;
-    bool live = __ballot(!done) != 0ull;  // wave-uniform
+    bool live = __ballot(T > 0.f) != 0ull;  // wave-uniform
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     uint32_t pid_g = 0;
@@ -90,23 +94,22 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float power2 = a.z * dx * dx + (b.x * dy * dy + a.w * dx * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool valid = !done && (power2 <= 0.0f) && (power2 >= b.z) && (alpha >= (1.0f / 255.0f));
-            const float test_T = T * (1.f - alpha);
-            const bool kill = valid && (test_T < 0.0001f);
-            const bool blend = valid && !kill;
-            const float w = blend ? alpha * T : 0.f;
+            const float al = fminf(0.99f, b.y * G);
+            const float a1 = (power2 <= 0.0f) ? al : 0.f;
+            const float a2 = (a1 >= (1.0f / 255.0f)) ? a1 : 0.f;  // alpha, or 0 if this pair is rejected
+            const float test_T = T * (1.f - a2);                  // == T for a rejected pair, < 0 for a frozen pixel
+            const bool pass = test_T >= 0.0001f;
+            const float wT = a2 * T;
+            const float w = pass ? wT : 0.f;                      // > 0 exactly when the pair is blended
+            T = pass ? test_T : -fabsf(T);                        // freeze: keeps |T| = final_T
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
-            T = blend ? test_T : T;
-            last = blend ? __float_as_uint(c.w) : last;
-            last_k = blend ? __float_as_uint(b.w) : last_k;
-            done = done || kill;
-            if (__ballot(kill) != 0ull) {
-                if (__ballot(!done) == 0ull) { live = false; break; }
-            }
+            const bool blended = w > 0.f;
+            last = blended ? __float_as_uint(c.w) : last;
+            last_k = blended ? __float_as_uint(b.w) : last_k;
         }
+        live = __ballot(T > 0.f) != 0ull;  // every pixel of the quadrant frozen: stop
     }
     {
         const uint32_t nm = wave_max_u32(last_k);
@@ -115,12 +118,13 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     if (inside) {
         const size_t HW = (size_t)H * W;
         const size_t pid = (size_t)py * W + px;
-        final_T[pid] = T;
+        const float Tf = fabsf(T);
+        final_T[pid] = Tf;
         n_contrib[pid] = last;
         ncon_c[pid] = last_k;
-        out_color[pid] = C0 + T * bg[0];
-        out_color[HW + pid] = C1 + T * bg[1];
-        out_color[2 * HW + pid] = C2 + T * bg[2];
+        out_color[pid] = C0 + Tf * bg[0];
+        out_color[HW + pid] = C1 + Tf * bg[1];
+        out_color[2 * HW + pid] = C2 + Tf * bg[2];
     }
 }
 
