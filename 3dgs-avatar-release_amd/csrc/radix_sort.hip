@@ -10,10 +10,11 @@
 
 // wave-level digit match: lanes holding the same 8-bit digit find each other with 8 ballots.
 // Returns the peer mask (lanes with my digit among the `valid` ones).
-__device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool valid) {
+__device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool valid, int dbits) {
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
+        if (b >= dbits) break;  // wave-uniform
         const bool bit = (digit >> b) & 1u;
         const unsigned long long bal = __ballot(bit);
         peers &= bit ? bal : ~bal;
@@ -25,7 +26,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
 // so runs of identical keys (tile ids in emission order, depth exponents) do not serialise on one
 // LDS address.
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
-                                                             uint32_t* __restrict__ hist, int nblk,
+                                                             int dbits, uint32_t* __restrict__ hist, int nblk,
                                                              uint32_t* __restrict__ totals) {
     __shared__ uint32_t h[256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = base + r * RS_THREADS + tid;
         const bool valid = i < n;
-        const uint32_t digit = valid ? ((keys[i] >> shift) & 255u) : 0u;
-        const unsigned long long peers = match_digit(digit, valid);
+        const uint32_t digit = valid ? ((keys[i] >> shift) & ((1u << dbits) - 1u)) : 0u;
+        const unsigned long long peers = match_digit(digit, valid, dbits);
         if (valid && (peers & lt_mask) == 0ull) atomicAdd(&h[digit], (uint32_t)__popcll(peers));
     }
     __syncthreads();
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                int64_t n, int shift, const uint32_t* __restrict__ hist,
-                                                                int nblk) {
+                                                                int64_t n, int shift, int dbits,
+                                                                const uint32_t* __restrict__ hist, int nblk) {
+    const uint32_t dmask = (1u << dbits) - 1u;
     __shared__ uint32_t whist[4][256];
     __shared__ uint32_t delta[256];
     __shared__ uint32_t wsum[4];
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t digit = (key[r] >> shift) & 255u;
-        const unsigned long long peers = match_digit(digit, valid);
+        const uint32_t digit = (key[r] >> shift) & dmask;
+        const unsigned long long peers = match_digit(digit, valid, dbits);
         const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
         const uint32_t seen = whist[wid][digit];
         lrank[r] = seen + rank;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = wbase + r * 64 + lane;
         if (i < n) {
-            const uint32_t lpos = whist[wid][(key[r] >> shift) & 255u] + lrank[r];
+            const uint32_t lpos = whist[wid][(key[r] >> shift) & dmask] + lrank[r];
             skey[lpos] = key[r];
             sval[lpos] = val[r];
         }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
         const int i = r * RS_THREADS + tid;
         if (i < nvalid) {
             const uint32_t k = skey[i];
-            const uint32_t pos = (uint32_t)i + delta[(k >> shift) & 255u];
+            const uint32_t pos = (uint32_t)i + delta[(k >> shift) & dmask];
             kout[pos] = k;
             vout[pos] = sval[i];
         }
@@ -184,19 +186,21 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, ui
     if (n <= 0) return GS_OK;
     const int nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
     const int passes = radix_passes(bits);
+    const int dbits = 8;  // (an equal 6 + 6 split of 12 tile bits measured no faster than 8 + 4)
     // per-pass digit totals live behind the [256][nblk] table (the layouts reserve 4 x 256 extra words)
     uint32_t* totals = hist + (size_t)256 * nblk;
     hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
     if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblk,
+        const int shift = dbits * p;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, dbits, hist, nblk,
                            totals + 256 * p);
         GS_LAUNCH_CHECK("sort.hist", debug, s);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, hist, nblk, totals + 256 * p);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << dbits), dim3(256), 0, s, hist, nblk, totals + 256 * p);
         GS_LAUNCH_CHECK("sort.scan", debug, s);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblk);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, dbits, hist,
+                           nblk);
         GS_LAUNCH_CHECK("sort.scatter", debug, s);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
