@@ -64,9 +64,18 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
     const uint32_t* __restrict__ clamped, const float4* __restrict__ sums, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
+    extern __shared__ float sh_tile[];  // SH rows of this workgroup: coefficients in, gradients out (in place)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const bool live = radii[i] > 0;
+    const int ld = sh_tile_ld(M);
+    const int row0 = blockIdx.x * blockDim.x;
+    const int nrows = min((int)blockDim.x, P - row0);
+    if (shs) {
+        sh_tile_load(shs + (size_t)row0 * M * 3, sh_tile, nrows, M * 3, ld);
+        __syncthreads();
+    }
+    const bool inb = i < P;
+    const bool live = inb && radii[i] > 0;
+    if (inb) {
 
     // ---- the nine 2-D gradient sums of this Gaussian (segment_reduce_kernel) ----
     float s[9];
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
         gm[2] += (PV[8] * mw - PV[11] * mul1) * g2x + (PV[9] * mw - PV[11] * mul2) * g2y;
         // (v) SH backward
         if (shs) {
-            const float* sh = shs + (size_t)i * M * 3;
-            float* gsh = dL_dsh + (size_t)i * M * 3;
+            float* sh = sh_tile + threadIdx.x * ld;  // coefficients, overwritten by their gradients
+            float* gsh = sh;
             const uint32_t cl = clamped[i];
             const float dox = mean.x - campos[0], doy = mean.y - campos[1], doz = mean.z - campos[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
@@ -173,7 +182,10 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const float g = ((cl >> c) & 1u) ? 0.f : gR[c];
-#define SHC(k) sh[(k) * 3 + c]
+                float shr[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) shr[k] = (k < (deg + 1) * (deg + 1)) ? sh[k * 3 + c] : 0.f;
+#define SHC(k) shr[k]
 #define GSH(k) gsh[(k) * 3 + c]
                 float dx = 0.f, dy = 0.f, dz = 0.f;
                 GSH(0) = SH_C0 * g;
@@ -256,8 +268,8 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
             gq[2] = 2 * x * (dR[0][1] + dR[1][0]) + 2 * r * (dR[0][2] - dR[2][0]) + 2 * z * (dR[2][1] + dR[1][2]) - 4 * y * (dR[2][2] + dR[0][0]);
             gq[3] = 2 * r * (dR[1][0] - dR[0][1]) + 2 * x * (dR[0][2] + dR[2][0]) + 2 * y * (dR[2][1] + dR[1][2]) - 4 * z * (dR[1][1] + dR[0][0]);
         }
-    } else if (dL_dsh) {
-        float* gsh = dL_dsh + (size_t)i * M * 3;
+    } else if (shs) {
+        float* gsh = sh_tile + threadIdx.x * ld;
         for (int k = 0; k < M * 3; k++) gsh[k] = 0.f;
     }
     dL_dmeans3D[3 * i] = gm[0];
@@ -271,6 +283,11 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
         dL_dscales[3 * i + 2] = gs[2];
     }
     if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    }  // inb
+    if (shs) {
+        __syncthreads();
+        sh_tile_store(dL_dsh + (size_t)row0 * M * 3, sh_tile, nrows, M * 3, ld);
+    }
 }
 
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
@@ -281,7 +298,8 @@ int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const flo
                        reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint32_t*>(qvalid),
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
-    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D,
+    const size_t lds = a.shs ? (size_t)256 * ((3 * a.M) | 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, a.P, a.sh_degree, a.M, a.means3D,
                        a.scales, a.scale_modifier, a.rotations, a.shs, a.cov3D_precomp, a.viewmatrix, a.projmatrix,
                        a.campos, a.W, a.H, a.tanfovx, a.tanfovy, fx, fy, radii, clamped,
                        reinterpret_cast<const float4*>(sums), g.dL_dmeans3D, g.dL_dmeans2D,

@@ -122,3 +122,33 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 mean, const fl
     *clamped = cl;
     return make_float3(out[0], out[1], out[2]);
 }
+
+// ---- SH tiles: the (M,3) coefficient block of Gaussian i is 3M contiguous floats, so a thread-per-
+// Gaussian kernel reading (or writing) it directly touches a different cache line per lane on every
+// access.  These helpers move a whole workgroup's rows between HBM and LDS with coalesced dword
+// accesses; in LDS a row has an ODD stride `ld`, so lanes walking the same column hit distinct banks.
+__device__ __forceinline__ int sh_tile_ld(int M) { return (3 * M) | 1; }
+__device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float* __restrict__ lds, int nrows, int rf,
+                                             int ld) {
+    const int total = nrows * rf;
+    int r = (int)threadIdx.x / rf, c = (int)threadIdx.x - r * rf;
+    const int dr = (int)blockDim.x / rf, dc = (int)blockDim.x - dr * rf;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        lds[r * ld + c] = g[e];
+        r += dr;
+        c += dc;
+        if (c >= rf) { c -= rf; r++; }
+    }
+}
+__device__ __forceinline__ void sh_tile_store(float* __restrict__ g, const float* __restrict__ lds, int nrows, int rf,
+                                              int ld) {
+    const int total = nrows * rf;
+    int r = (int)threadIdx.x / rf, c = (int)threadIdx.x - r * rf;
+    const int dr = (int)blockDim.x / rf, dc = (int)blockDim.x - dr * rf;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        g[e] = lds[r * ld + c];
+        r += dr;
+        c += dc;
+        if (c >= rf) { c -= rf; r++; }
+    }
+}

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
 
     float V[16], PV[16];
@@ -100,6 +100,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
     const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
     const int blocks = (a.P + 255) / 256;
+    // (staging the SH rows through LDS for coalescing measured slower here: the kernel is latency-bound)
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.scales,
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
