@@ -1,0 +1,73 @@
+"""C-ABI library on the CPU (no GPU needed): it loads, exports every symbol include/gsplat_mi355.h declares,
+its size functions and argument validation run without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gsplat_mi355 import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gsplat_build", os.path.join(ROOT, "3dgs-avatar-release_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "gsplat_mi355.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:gs|knn)_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 18
+    L = lib.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(lib.EXPORTS)
+
+
+def test_size_functions_and_status_strings(lib):
+    L = lib.load()
+    g1, g2 = lib.nbytes(L.gs_geom_bytes, 1000), lib.nbytes(L.gs_geom_bytes, 200000)
+    assert 0 < g1 < g2 and g2 >= 200000 * 48
+    assert lib.nbytes(L.gs_image_bytes, 1024, 1024) >= 1024 * 1024 * 12
+    b = lib.nbytes(L.gs_binning_bytes, 5_000_000, 1024, 1024)
+    assert b >= 5_000_000 * 16
+    s = lib.nbytes(L.gs_backward_scratch_bytes, 5_000_000, 200000, 1024, 1024)
+    assert s >= 5_000_000 * 4 * 48
+    assert lib.nbytes(L.knn_workspace_bytes, 50000) > 50000 * 16
+    for code in (0, -1, -2, -3, -4, -5):
+        assert len(L.gs_status_string(code)) > 0
+    out = ctypes.c_size_t(0)
+    assert L.gs_binning_bytes(1 << 40, 64, 64, ctypes.byref(out)) == -3  # GS_E_TOO_LARGE
+    assert L.gs_geom_bytes(-1, ctypes.byref(out)) == -1                    # GS_E_BAD_ARG
+    assert b"gfx950" in L.gs_build_info()
+
+
+def test_argument_validation_without_a_device(lib):
+    """Exclusivity / null checks are done on the host before any HIP call."""
+    L = lib.load()
+    a = lib.GsFwdArgs()
+    a.P, a.W, a.H, a.sh_degree, a.M = 10, 64, 64, 0, 1
+    fake = 0x1000  # never dereferenced: validation fails first
+    a.bg = a.viewmatrix = a.projmatrix = a.campos = a.means3D = a.opacities = fake
+    a.shs = fake
+    a.colors_precomp = fake  # both colour inputs -> GS_E_EXCLUSIVE
+    a.scales = a.rotations = fake
+    rc = L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None)
+    assert rc == -2
+    a.colors_precomp = None
+    a.cov3D_precomp = fake  # both covariance inputs
+    assert L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None) == -2
+    a.cov3D_precomp = None
+    a.sh_degree = 3  # M too small for the degree
+    assert L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None) == -1
+    a.sh_degree = 0
+    assert L.gs_forward_preprocess(ctypes.byref(a), fake, 16, fake, 1 << 30, fake, None, None) == -5  # workspace too small
+    with pytest.raises(RuntimeError, match="exactly one of"):
+        lib.check(-2)

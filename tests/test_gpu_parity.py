@@ -277,3 +277,61 @@ def test_full_size_properties_config2_50k_512(oracle):
     fw = oracle.forward(sc)
     assert np.array_equal(st["radii"], fw["radii"]) and np.array_equal(pl, fw["binning"]["point_list"])
     _bulk_close(st["color"], fw["color"], name="color 50k/512")
+
+
+def test_heavy_tail_stress_config5_shape(oracle):
+    """BASELINE config 5 in miniature: 5 % of the Gaussians with 4x scales (long per-tile lists, many
+    64-entry chunks per quadrant), non-zero background, precomputed covariances."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n, W, H = 12000, 320, 208
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=77, heavy_tail=0.05, scale_mul=1.6)
+    bg = (0.4, 0.1, 0.7)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, cov_mode="cov")
+    fw = oracle.forward(sc)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), cov3D_precomp=cloud.covariance6().to(dev))
+    assert st["D"] == fw["binning"]["D"] and st["D"] > 40 * n
+    assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"])
+    r = fw["binning"]["ranges"]
+    assert (r[:, 1] - r[:, 0]).max() > 2000  # tiles with long lists
+    _bulk_close(st["color"], fw["color"], name="color")
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9))
+    want = oracle.backward(sc, fw, gimg.numpy())
+    means3D = cloud.xyz.to(dev).requires_grad_(True)
+    means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+    opac = cloud.opacity.to(dev).requires_grad_(True)
+    shs = cloud.shs.to(dev).requires_grad_(True)
+    cov = cloud.covariance6().to(dev).requires_grad_(True)
+    color, radii = GaussianRasterizer(_settings(cam, cloud, bg, dev))(means3D=means3D, means2D=means2D, opacities=opac,
+                                                                     shs=shs, cov3D_precomp=cov)
+    (color * gimg.to(dev)).sum().backward()
+    for name, t in (("means3D", means3D), ("means2D", means2D), ("opacities", opac), ("sh", shs), ("cov3D_precomp", cov)):
+        _bulk_close(t.grad.cpu().numpy(), want[name].reshape(t.shape), tol=2e-5, frac=2e-4, name=name)
+
+
+def test_bitwise_determinism_and_debug_mode():
+    """No atomics anywhere in the path: two runs give bit-identical images and gradients; debug=True
+    (synchronise + check after every kernel) gives the same bits."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 6000, 256, 192
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=13, scale_mul=1.4)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = []
+    for dbg in (False, False, True):
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        shs = cloud.shs.to(dev).requires_grad_(True)
+        scales = cloud.scales.to(dev).requires_grad_(True)
+        rot = cloud.rotations.to(dev).requires_grad_(True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        rast = GaussianRasterizer(_settings(cam, cloud, (0.1, 0.2, 0.3), dev, debug=dbg))
+        color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rot)
+        (color * gimg).sum().backward()
+        outs.append([color.detach().clone(), radii.clone(), means3D.grad, means2D.grad, shs.grad, scales.grad, rot.grad,
+                     opac.grad])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
