@@ -117,27 +117,58 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
 // Emission of the (tile id, Gaussian index) pairs in depth-rank order, tiles y-outer / x-inner
 // (the upstream duplicateWithKeys order).  Also records each Gaussian's first pair index in its
 // splat record (slot 9): the backward pass addresses its per-pair gradient rows through it.
+// Wave-cooperative: a wave owns 64 consecutive ranks, i.e. one CONTIGUOUS span of output pairs; its
+// lanes walk that span 64 pairs at a time (fully coalesced stores) and find each pair's owner with a
+// 6-step binary search over the lanes' first-pair offsets (lane shuffles).
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ sorted_idx,
                                                    const uint32_t* __restrict__ tt_rank,
                                                    const uint32_t* __restrict__ offs, float* __restrict__ rec,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int P,
                                                    int gx) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t tt = tt_rank[r];
-    if (tt == 0) return;
-    const uint32_t idx = sorted_idx[r];
-    uint32_t off = offs[r];
-    float* R = rec + (size_t)idx * REC_F;
-    R[9] = __uint_as_float(off);
-    const uint32_t rmin = __float_as_uint(R[10]), rsz = __float_as_uint(R[11]);
-    const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu, h = rsz >> 16;
-    for (uint32_t y = miny; y < miny + h; y++)
-        for (uint32_t x = minx; x < minx + w; x++) {
-            keys[off] = y * (uint32_t)gx + x;
-            vals[off] = idx;
-            off++;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;  // rank handled by this lane (a wave = 64 ranks)
+    const int lane = threadIdx.x & 63;
+    uint32_t tt = 0, off = 0xFFFFFFFFu, idx = 0, rmin = 0, rsz = 0;
+    if (r < P) {
+        tt = tt_rank[r];
+        off = offs[r];
+        idx = sorted_idx[r];
+        if (tt) {
+            float* R = rec + (size_t)idx * REC_F;
+            R[9] = __uint_as_float(off);
+            rmin = __float_as_uint(R[10]);
+            rsz = __float_as_uint(R[11]);
         }
+    }
+    const uint32_t start = __shfl(off, 0, 64);  // ranks are in range for lane 0 of every launched wave
+    // one past the wave's last pair: offset + count of the last lane that has a rank
+    const int last = min(63, P - 1 - (r - lane));
+    const uint32_t end = __shfl(off, last, 64) + __shfl(tt, last, 64);
+    for (uint32_t o = start + (uint32_t)lane; o - (uint32_t)lane < end; o += 64) {
+        const bool act = o < end;
+        // owner: the largest lane j <= last with off_j <= o (offsets are non-decreasing; empty Gaussians
+        // share their successor's offset, so the largest such lane is the one that owns pair o)
+        int lo = 0, hi = last;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi + 1) >> 1;
+            const uint32_t om = __shfl(off, mid, 64);
+            if (om <= o) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t o_off = __shfl(off, lo, 64);
+        const uint32_t o_idx = __shfl(idx, lo, 64);
+        const uint32_t o_rmin = __shfl(rmin, lo, 64);
+        const uint32_t o_rsz = __shfl(rsz, lo, 64);
+        if (act) {
+            const uint32_t w = o_rsz & 0xFFFFu;
+            const uint32_t li = o - o_off;
+            uint32_t y = (uint32_t)(((float)li + 0.5f) / (float)w);
+            if (y * w > li) y--;
+            if ((y + 1) * w <= li) y++;
+            const uint32_t x = li - y * w;
+            keys[o] = ((o_rmin >> 16) + y) * (uint32_t)gx + (o_rmin & 0xFFFFu) + x;
+            vals[o] = o_idx;
+        }
+    }
 }
 
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,

@@ -36,6 +36,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _tls = threading.local()
+_last_count = {}  # (device, P, W, H) -> num_rendered of the previous call: a sizing hint only
 
 
 def _pinned_count(device):
@@ -124,11 +125,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             count = _pinned_count(dev)
             _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), geom_bytes, img.data_ptr(), img_bytes,
                                                radii.data_ptr(), count.data_ptr(), sptr))
+            # allocate for the expected pair count while phase 1 runs, so that only kernel launches are
+            # left to do once the count is known (the GPU idles between the sync and the first launch)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            guess = _last_count.get((dev.index, P, W, H), 0)
+            bin_bytes = _lib.nbytes(L.gs_binning_bytes, guess + guess // 8, W, H) if guess else 0
+            binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if guess else None
             stream.synchronize()  # the one host sync of the forward: the size of the pair list
             num_rendered = int(count.item())
-            bin_bytes = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
-            binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            _last_count[(dev.index, P, W, H)] = num_rendered
+            need = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
+            if binning is None or bin_bytes < need:
+                bin_bytes = need
+                binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
             _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
                                            img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr))
         ctx.raster_settings = raster_settings

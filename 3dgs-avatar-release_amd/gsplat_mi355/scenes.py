@@ -61,8 +61,8 @@ class GaussianCloud(object):
         m = (sh_degree + 1) ** 2
         sizes = [3 * n, 3 * n, 4 * n, n, 3 * m * n]
         parts = torch.split(flat, sizes)
-        return GaussianCloud(parts[0].view(n, 3), parts[1].view(n, 3), parts[2].view(n, 4), parts[3].view(n, 1),
-                             parts[4].view(n, m, 3), sh_degree)
+        return GaussianCloud(parts[0].view(n, 3).clone(), parts[1].view(n, 3).clone(), parts[2].view(n, 4).clone(),
+                             parts[3].view(n, 1).clone(), parts[4].view(n, m, 3).clone(), sh_degree)
 
 
 def synthetic_cloud(n, sh_degree=3, seed=0, dist2_fn=None, heavy_tail=0.0, device="cpu"):
