@@ -187,6 +187,52 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     return GS_OK;
 }
 
+int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,
+                      void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t D, float* out_color,
+                      void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!geom_src || !img_src || !geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
+    const GeomLayout L = geom_layout(a->P);
+    const ImgLayout I = img_layout(a->W, a->H);
+    const BinLayout B = bin_layout(D);
+    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const char* gs = (const char*)geom_src;
+    const char* is = (const char*)img_src;
+    char* g = (char*)geom;
+    char* b = (char*)binning;
+    char* im = (char*)img;
+    const int ntiles = I.gx * I.gy;
+    if (a->P > 0) {
+        StageScope sc_("recolor", s);
+        rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
+                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), s);
+        if (rc != GS_OK) return rc;
+    }
+    // the new image state needs its own copy of the tile ranges and launch order (its backward reads them)
+    hipError_t e = hipMemcpyAsync(im + I.ranges, is + I.ranges, (size_t)ntiles * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(im + I.order, is + I.order, (size_t)ntiles * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { gs_set_error((int)e, "shared.copy"); return GS_E_HIP; }
+    const bool odd = radix_passes(tile_bits(ntiles)) & 1;
+    const uint32_t* point_list = D > 0 ? (const uint32_t*)(b + (odd ? B.val1 : B.val0)) : nullptr;
+    QuadLists ql;
+    ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // rewritten with identical content (same geometry)
+    ql.ncon_c = (uint32_t*)(im + I.ncon_c);
+    ql.qcount = (uint32_t*)(im + I.tile_nmax);
+    ql.qstaged = (uint32_t*)(im + I.qstaged);
+    { StageScope sc_("render_fwd", s);
+    rc = launch_render_forward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges),
+                               (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
+                               (uint32_t*)(im + I.n_contrib), ql, s); }
+    if (rc != GS_OK) return rc;
+    if (a->debug) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { gs_set_error((int)e, "render_forward"); return GS_E_HIP; }
+    }
+    return GS_OK;
+}
+
 int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
                 const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {

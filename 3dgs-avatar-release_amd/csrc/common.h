@@ -120,6 +120,8 @@ struct StageScope {
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, hipStream_t s);
+int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between

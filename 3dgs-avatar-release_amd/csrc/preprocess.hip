@@ -109,6 +109,50 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
     return GS_OK;
 }
 
+// Shared-geometry second render: same Gaussians, camera and covariances as a
+// previous call, new colours.  Copies the per-Gaussian state the later stages read (splat record,
+// tiles touched) and replaces the colour (and the SH clamp mask).
+__global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, const float* __restrict__ means3D,
+                                                      const float* __restrict__ shs,
+                                                      const float* __restrict__ colors_precomp,
+                                                      const float* __restrict__ campos,
+                                                      const float4* __restrict__ rec_src,
+                                                      const uint32_t* __restrict__ tiles_src,
+                                                      float4* __restrict__ rec_dst, uint32_t* __restrict__ tiles_dst,
+                                                      uint32_t* __restrict__ clamped_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float4 r0 = rec_src[(size_t)i * 3], r1 = rec_src[(size_t)i * 3 + 1], r2 = rec_src[(size_t)i * 3 + 2];
+    const uint32_t tt = tiles_src[i];
+    uint32_t cl = 0;
+    if (tt) {
+        float3 col;
+        if (colors_precomp) {
+            col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
+        } else {
+            const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+            col = sh_to_rgb(deg, p, make_float3(campos[0], campos[1], campos[2]), shs + (size_t)i * M * 3, &cl);
+        }
+        r1.z = col.x;
+        r1.w = col.y;
+        r2.x = col.z;
+    }
+    rec_dst[(size_t)i * 3] = r0;
+    rec_dst[(size_t)i * 3 + 1] = r1;
+    rec_dst[(size_t)i * 3 + 2] = r2;
+    tiles_dst[i] = tt;
+    clamped_dst[i] = cl;
+}
+
+int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s) {
+    hipLaunchKernelGGL(recolor_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.shs,
+                       a.colors_precomp, a.campos, reinterpret_cast<const float4*>(rec_src), tiles_src,
+                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst);
+    GS_LAUNCH_CHECK("recolor", a.debug, s);
+    return GS_OK;
+}
+
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
                                                            const float* __restrict__ viewmatrix,
                                                            uint8_t* __restrict__ present) {

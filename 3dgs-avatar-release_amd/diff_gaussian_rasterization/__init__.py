@@ -35,7 +35,52 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+import os
+
 _tls = threading.local()
+_SHARE = os.environ.get("GSPLAT_SHARE_GEOMETRY", "1") != "0"
+
+
+class _GeomCache(object):
+    """State of the most recent forward per device, kept so that an immediately following call with
+    the SAME geometry tensors and camera but different colours (the reference's opacity pass,
+    gaussian_renderer/__init__.py:131-142) can skip preprocess, sorts and binning.
+    Matching is by storage address + autograd version counter (shared by every view of a storage);
+    the cache holds the tensors, so their storage cannot be freed and recycled under it."""
+
+    def __init__(self):
+        self.entry = {}
+
+    @staticmethod
+    def _sig(t):
+        return None if t is None else (t, t.data_ptr(), t._version, t.numel())
+
+    def key(self, settings, means3D, opacities, scales, rotations, cov3D):
+        return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
+                             float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0])),
+                    tensors=[self._sig(t) for t in (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix,
+                                                    settings.projmatrix, settings.campos)])
+
+    @staticmethod
+    def same(a, b):
+        if a["scalars"] != b["scalars"]:
+            return False
+        for x, y in zip(a["tensors"], b["tensors"]):
+            if (x is None) != (y is None):
+                return False
+            if x is not None and x[1:] != y[1:]:
+                return False
+        return True
+
+    def lookup(self, dev, key):
+        e = self.entry.get(dev.index)
+        return e if e is not None and self.same(e["key"], key) else None
+
+    def store(self, dev, key, **state):
+        self.entry[dev.index] = dict(key=key, **state)
+
+
+_geom_cache = _GeomCache()
 _last_count = {}  # (device, P, W, H) -> num_rendered of the previous call: a sizing hint only
 
 
@@ -122,6 +167,21 @@ class _RasterizeGaussians(torch.autograd.Function):
             geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
+            gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if _SHARE else None
+            hit = _geom_cache.lookup(dev, gkey) if _SHARE else None
+            if hit is not None:
+                # same geometry and camera as the previous call: new colours only
+                num_rendered = hit["num_rendered"]
+                binning = hit["binning"]
+                bin_bytes = binning.numel()
+                radii.copy_(hit["radii"])
+                color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+                _lib.check(L.gs_forward_shared(ctypes.byref(a), hit["geom"].data_ptr(), hit["img"].data_ptr(),
+                                               geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes, img.data_ptr(),
+                                               img_bytes, num_rendered, color.data_ptr(), sptr))
+                return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp,
+                                                   opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
+                                                   img, color, dev)
             count = _pinned_count(dev)
             _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), geom_bytes, img.data_ptr(), img_bytes,
                                                radii.data_ptr(), count.data_ptr(), sptr))
@@ -140,6 +200,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                 binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
             _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
                                            img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr))
+            if _SHARE:
+                _geom_cache.store(dev, gkey, geom=geom, binning=binning, img=img, num_rendered=num_rendered, radii=radii)
+        return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,
+                                           scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color, dev)
+
+    @staticmethod
+    def _finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, radii, geom, binning, img, color, dev):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)

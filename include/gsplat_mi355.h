@@ -101,6 +101,16 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                       void* img, size_t img_bytes, int64_t num_rendered, float* out_color, void* stream);
 
+/* ---- shared-geometry forward (no upstream counterpart).  The reference's render()
+ * rasterizes twice per step with identical geometry -- colour pass, then an opacity pass with
+ * colors = 1 (gaussian_renderer/__init__.py:121-142).  Given the geom / binning / image state of a
+ * previous gs_forward_* call on the SAME means3D, opacities, covariance inputs and camera, this renders
+ * new colours (a->shs or a->colors_precomp) without repeating preprocess, sorts and binning: it fills
+ * a fresh geom / image state (usable by gs_backward) and shares the binning state. */
+int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,
+                      void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t num_rendered,
+                      float* out_color, void* stream);
+
 /* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
  * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `scratch` holds
  * gs_backward_scratch_bytes(num_rendered, P, W, H) bytes. */

@@ -335,3 +335,57 @@ def test_bitwise_determinism_and_debug_mode():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_shared_geometry_second_render_is_bitwise_identical(oracle):
+    """the opacity pass of render() (same geometry, colours = 1) reuses the first
+    call's preprocess / sort / binning.  Its image and gradients must equal the stand-alone call's bit
+    for bit, and in-place changes of the geometry must invalidate the reuse."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 5000, 192, 160
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=17, scale_mul=1.3)
+    settings = _settings(cam, cloud, (0.0, 0.0, 0.0), dev)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(share):
+        dgr._SHARE = share
+        dgr._geom_cache.entry.clear()
+        xyz = cloud.xyz.to(dev).requires_grad_(True)
+        m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
+        op = cloud.opacity.to(dev).requires_grad_(True)
+        cov = cloud.covariance6().to(dev).requires_grad_(True)
+        cols = helpers.precomp_colors(cloud, cam).to(dev).requires_grad_(True)
+        ones = torch.ones(n, 3, device=dev)
+        rast = GaussianRasterizer(settings)
+        img1, r1 = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=cols, cov3D_precomp=cov)
+        hits_before = dgr._geom_cache.lookup(dev, dgr._geom_cache.key(settings, xyz, op.reshape(-1, 1), None, None, cov)) is not None
+        img2, r2 = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        ((img1 * gimg).sum() + (img2[:1] * gimg[:1]).sum()).backward()
+        return [img1.detach(), img2.detach(), r1, r2, xyz.grad, m2d.grad, op.grad, cov.grad, cols.grad], hits_before
+
+    try:
+        shared, hit = run(True)
+        alone, _ = run(False)
+        assert hit
+        for a, b in zip(shared, alone):
+            assert torch.equal(a, b)
+        # opacity render = 1 - T for a black background (gaussian_renderer/__init__.py:131-142)
+        sc1 = helpers.oracle_scene(cloud, cam, color_mode="precomp", colors=torch.ones(n, 3), cov_mode="cov")
+        _bulk_close(shared[1].cpu().numpy(), oracle.forward(sc1)["color"], name="opacity pass")
+        # an in-place update of the positions must not be served from the cache
+        dgr._SHARE = True
+        dgr._geom_cache.entry.clear()
+        xyz = cloud.xyz.to(dev)
+        op, cov = cloud.opacity.to(dev), cloud.covariance6().to(dev)
+        ones = torch.ones(n, 3, device=dev)
+        rast = GaussianRasterizer(settings)
+        with torch.no_grad():
+            a1, _ = rast(means3D=xyz, means2D=xyz, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+            xyz.add_(0.05)
+            a2, _ = rast(means3D=xyz, means2D=xyz, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        assert not torch.equal(a1, a2)
+    finally:
+        dgr._SHARE = True
+        dgr._geom_cache.entry.clear()
