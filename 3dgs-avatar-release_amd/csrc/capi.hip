@@ -175,7 +175,6 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
-    ql.qstaged = (uint32_t*)(im + I.qstaged);
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -220,7 +219,6 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // rewritten with identical content (same geometry)
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
-    ql.qstaged = (uint32_t*)(im + I.qstaged);
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges),
                                (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
@@ -260,7 +258,6 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         ql.qlist = (uint32_t*)(b + B.qlist);
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
-        ql.qstaged = (uint32_t*)(im + I.qstaged);
         uint8_t* qvalid = (uint8_t*)scratch + scratch_rows_bytes(D);
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         {

@@ -67,7 +67,7 @@ static inline BinLayout bin_layout(int64_t D) {
 }
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, qstaged, order, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, total;
     int gx, gy;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -81,7 +81,6 @@ static inline ImgLayout img_layout(int W, int H) {
     L.final_T = take((size_t)W * H * 4);
     L.ncon_c = take((size_t)W * H * 4);            // per pixel: last contributor in its quadrant's COMPACTED list
     L.tile_nmax = take((size_t)L.gx * L.gy * 16);  // per quadrant: compacted entries up to the last contributor
-    L.qstaged = take((size_t)L.gx * L.gy * 16);    // per quadrant: compacted entries the forward staged
     L.order = take((size_t)L.gx * L.gy * 4);
     L.total = o;
     return L;
@@ -142,7 +141,6 @@ struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
-    uint32_t* qstaged;  // [tiles][4]
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
