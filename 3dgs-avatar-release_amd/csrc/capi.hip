@@ -78,7 +78,7 @@ int gs_image_bytes(int32_t W, int32_t H, size_t* out) {
 }
 int gs_binning_bytes(int64_t D, int32_t W, int32_t H, size_t* out) {
     if (!out || D < 0 || W <= 0 || H <= 0) return GS_E_BAD_ARG;
-    if (D > 0xFFFFFFFFll) return GS_E_TOO_LARGE;
+    if (D > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     *out = bin_layout(D).total;
     return GS_OK;
 }
@@ -134,7 +134,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
-    if (D > 0xFFFFFFFFll) return GS_E_TOO_LARGE;
+    if (D > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const GeomLayout L = geom_layout(a->P);
     const ImgLayout I = img_layout(a->W, a->H);
     const BinLayout B = bin_layout(D);

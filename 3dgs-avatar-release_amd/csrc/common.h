@@ -8,6 +8,7 @@
 #define TILE 16                 // tile edge in pixels (parity contract: 16x16)
 #define WAVE 64                 // CDNA wavefront
 #define REC_F 12                // floats per splat record (48 B = 3 x 16 B)
+#define GS_MAX_PAIRS 0x3FFFFFFFll  // (tile, Gaussian) pairs per frame: 4 * pair + quadrant must fit 32 bits
 
 // ---------------------------------------------------------------------------------------------
 // State-buffer layouts.  Pure functions of (P) / (D, W, H) / (W, H): every call re-derives the
