@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         const bool sw = lane == t;
         if (sw && has) {
             // this lane has seen all 64 pixels with its entry: park the row
-            rowbuf[t * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            rowbuf[t * 3] = make_float4(2.f * cur.A2 * acc[0] + cur.B2 * acc[1], 2.f * cur.C2 * acc[1] + cur.B2 * acc[0],
+                                        acc[2], acc[3]);
             rowbuf[t * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
             rowbuf[t * 3 + 2] = make_float4(acc[8], __uint_as_float(cur_row), 0.f, 0.f);
             pend = true;
@@ -179,26 +180,26 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             // forward's relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
             const float a1 = (power2 <= 0.0f) ? al : 0.f;
             const float a2 = (k < ncon) ? a1 : 0.f;
-            const float alpha = (a2 >= (1.0f / 255.0f)) ? a2 : 0.f;
+            const bool valid = a2 >= (1.0f / 255.0f);
+            const float alpha = valid ? a2 : 0.f;
+            const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
             const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
             Pfx += cg * wgt;
             const float one_m = 1.f - alpha;
             const float dL_dalpha = T * cg - (g.w - Pfx) * __builtin_amdgcn_rcpf(one_m);
             T *= one_m;
-            const float Gd = (alpha > 0.f) ? G * dL_dalpha : 0.f;
+            const float Gd = Gv * dL_dalpha;
             const float tt = cur.o * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
-            const float u = 2.f * cur.A2 * dx + cur.B2 * dy;
-            const float v = 2.f * cur.C2 * dy + cur.B2 * dx;
-            const float tdx = tt * dx;
-            // sums (constant factors applied when the row is stored):
-            //  0: t*u -> dL/dmean.x * log2e   1: t*v   2: t dx^2  3: t dx dy  4: t dy^2 (-> -2 dL/dconic)
-            //  5: G dL/dalpha = dL/dopacity   6..8: w g_c = dL/dcolor
-            acc[0] += tt * u;
-            acc[1] += tt * v;
+            const float tdx = tt * dx, tdy = tt * dy;
+            // sums (the conic / mean combinations and constant factors are applied when the row is stored):
+            //  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
+            //  6..8: w g_c = dL/dcolor
+            acc[0] += tdx;
+            acc[1] += tdy;
             acc[2] += tdx * dx;
             acc[3] += tdx * dy;
-            acc[4] += tt * dy * dy;
+            acc[4] += tdy * dy;
             acc[5] += Gd;
             acc[6] += wgt * g.x;
             acc[7] += wgt * g.y;
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     store_pending();
     if (has) {
         const size_t row = cur_row;
-        qrows[row * 3] = make_float4(acc[0] * il2, acc[1] * il2, -0.5f * acc[2], -0.5f * acc[3]);
+        const float mx = 2.f * cur.A2 * acc[0] + cur.B2 * acc[1], my = 2.f * cur.C2 * acc[1] + cur.B2 * acc[0];
+        qrows[row * 3] = make_float4(mx * il2, my * il2, -0.5f * acc[2], -0.5f * acc[3]);
         qrows[row * 3 + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
         qrows[row * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
         qvalid[row] = 1;
