@@ -17,6 +17,12 @@
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 #define SORT_ITEMS 4096          // elements per radix-sort block (256 threads x 16)
+#define SORT_SMALL_N (1 << 20)   // sorts up to this size use 1024-element blocks instead
+// number of [256]-row table columns a sort of n elements needs (either block size) + 4 rows of totals
+static inline size_t sort_table_words(size_t n) {
+    const size_t items = n <= (size_t)SORT_SMALL_N ? 1024 : SORT_ITEMS;
+    return (size_t)256 * ((n + items - 1) / items + 4);
+}
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
 struct GeomLayout {
@@ -41,7 +47,7 @@ static inline GeomLayout geom_layout(int P) {
     L.tt_rank = take(n * 4);
     L.offs = take(n * 4);
     L.bsum = take((size_t)(L.nblk_scan + 1) * 4);
-    L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
+    L.hist = take(sort_table_words(n) * 4);
     L.count = take(64);
     L.total = o;
     return L;
@@ -61,7 +67,7 @@ static inline BinLayout bin_layout(int64_t D) {
     L.key1 = take(n * 4);
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
-    L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
+    L.hist = take(sort_table_words(n) * 4);
     L.qlist = take(n * 16);  // per quadrant: compacted Gaussian indices the forward visited
     L.total = o;
     return L;

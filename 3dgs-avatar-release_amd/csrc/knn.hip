@@ -28,7 +28,7 @@ static KnnLayout knn_layout(int P) {
     L.key1 = take(n * 4);
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
-    L.hist = take((size_t)256 * (L.nblk_sort + 4) * 4);
+    L.hist = take(sort_table_words(n) * 4);
     L.pts = take(n * 16);
     L.boxes = take((size_t)L.nbox * 32);
     L.minmax = take(64);

@@ -6,7 +6,8 @@
 #include "common.h"
 
 #define RS_THREADS 256
-#define RS_ROUNDS (SORT_ITEMS / RS_THREADS)
+#define RS_ROUNDS_BIG (SORT_ITEMS / RS_THREADS)  // 16 keys per thread: large sorts
+#define RS_ROUNDS_SMALL 4                      // 4 keys per thread: small sorts finish sooner on more CUs
 
 // wave-level digit match: lanes holding the same 8-bit digit find each other with 8 ballots.
 // Returns the peer mask (lanes with my digit among the `valid` ones).
@@ -25,6 +26,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
 // Per-block digit histogram.  Equal digits inside a wave are matched first and counted by one lane,
 // so runs of identical keys (tile ids in emission order, depth exponents) do not serialise on one
 // LDS address.
+template <int RS_ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                              int dbits, uint32_t* __restrict__ hist, int nblk,
                                                              uint32_t* __restrict__ totals) {
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     const int tid = threadIdx.x, lane = tid & 63;
     h[tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    const int64_t base = (int64_t)blockIdx.x * (RS_ROUNDS * RS_THREADS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll 4
     for (int r = 0; r < RS_ROUNDS; r++) {
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
 // block-sorted order (start offset + rank).  Phase 4:
 // the block writes the parked pairs out linearly, so every digit's run leaves as one contiguous,
 // coalesced burst (position = local index + delta[digit]).
+template <int RS_ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -103,14 +106,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     __shared__ uint32_t whist[4][256];
     __shared__ uint32_t delta[256];
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t skey[SORT_ITEMS];
-    __shared__ uint32_t sval[SORT_ITEMS];
+    constexpr int ITEMS = RS_ROUNDS * RS_THREADS;
+    __shared__ uint32_t skey[ITEMS];
+    __shared__ uint32_t sval[ITEMS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) whist[w][tid] = 0;
-    const int64_t bbase = (int64_t)blockIdx.x * SORT_ITEMS;
-    const int64_t wbase = bbase + wid * (SORT_ITEMS / 4);
-    const int nvalid = (int)((n - bbase) < (int64_t)SORT_ITEMS ? (n - bbase) : (int64_t)SORT_ITEMS);
+    const int64_t bbase = (int64_t)blockIdx.x * ITEMS;
+    const int64_t wbase = bbase + wid * (ITEMS / 4);
+    const int nvalid = (int)((n - bbase) < (int64_t)ITEMS ? (n - bbase) : (int64_t)ITEMS);
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
@@ -181,30 +185,39 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     }
 }
 
-int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                      int debug, hipStream_t s) {
-    if (n <= 0) return GS_OK;
-    const int nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+template <int RS_ROUNDS>
+static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
+                           int debug, hipStream_t s) {
+    const int items = RS_ROUNDS * RS_THREADS;
+    const int nblk = (int)((n + items - 1) / items);
     const int passes = radix_passes(bits);
     const int dbits = 8;  // (an equal 6 + 6 split of 12 tile bits measured no faster than 8 + 4)
-    // per-pass digit totals live behind the [256][nblk] table (the layouts reserve 4 x 256 extra words)
+    // per-pass digit totals live behind the [256][nblk] table (the layouts reserve room for them)
     uint32_t* totals = hist + (size_t)256 * nblk;
     hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
     if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
         const int shift = dbits * p;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, dbits, hist, nblk,
+        hipLaunchKernelGGL(rs_hist_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, dbits, hist, nblk,
                            totals + 256 * p);
         GS_LAUNCH_CHECK("sort.hist", debug, s);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << dbits), dim3(256), 0, s, hist, nblk, totals + 256 * p);
         GS_LAUNCH_CHECK("sort.scan", debug, s);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, dbits, hist,
-                           nblk);
+        hipLaunchKernelGGL(rs_scatter_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift,
+                           dbits, hist, nblk);
         GS_LAUNCH_CHECK("sort.scatter", debug, s);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
     }
     return GS_OK;
+}
+
+int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
+                      int debug, hipStream_t s) {
+    if (n <= 0) return GS_OK;
+    // SORT_SMALL_N and the table sizes in the layouts (common.h) go together
+    if (n <= SORT_SMALL_N) return sort_pairs_impl<RS_ROUNDS_SMALL>(k0, v0, k1, v1, hist, n, bits, debug, s);
+    return sort_pairs_impl<RS_ROUNDS_BIG>(k0, v0, k1, v1, hist, n, bits, debug, s);
 }
