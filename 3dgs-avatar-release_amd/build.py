@@ -20,6 +20,9 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-fhip-fp32-co
           "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # translation units whose integer outputs must match the CPU oracle bit for bit: no FMA contraction
 STRICT = {"preprocess.hip", "knn.hip"}
+# packed fp32 (v_pk_*) issues at half rate on gfx950 (tools/valu_rate.hip), so pairing scalars buys
+# nothing and the register shuffling the SLP vectoriser adds to form the pairs costs VALU slots
+NO_SLP = {"render_fwd.hip", "render_bwd.hip"}
 SOURCES = ["capi.hip", "preprocess.hip", "radix_sort.hip", "binning.hip", "render_fwd.hip", "render_bwd.hip",
            "gaussian_bwd.hip", "knn.hip"]
 
@@ -47,6 +50,8 @@ def build(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         flags = list(COMMON) + (["-ffp-contract=off"] if src in STRICT else ["-ffp-contract=fast"])
+        if src in NO_SLP:
+            flags.append("-fno-slp-vectorize")
         cmd = [cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ qrows, uint8_t* __restrict__ qvalid) {
-    __shared__ float4 rowbuf[64 * 3];  // finished rows waiting for the bulk store: 9 sums + row index
-    __shared__ float4 pix[64 * 2];     // per-pixel constants
+    __shared__ float4 rowbuf[64 * 4];  // finished entries (nine sums + conic, opacity) waiting for the bulk store
+    __shared__ float4 pix[128 * 2];    // per-pixel constants, stored twice so a round's reads never wrap
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -63,16 +63,20 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     if (m == 0) return;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-        float4 c0 = zero4, c1 = make_float4((float)px, (float)py, 0.f, 0.f);
+        // (g0, g1, g2, Gtot) and (x, y, lim): pixel p meets compacted entry k at step s = k + p, and the
+        // pair counts only while k < (its last contributor) <=> s < lim = ncon + p
+        float4 c0 = zero4, c1 = make_float4((float)px, (float)py, __uint_as_float((uint32_t)lane), 0.f);
         if (px < W && py < H) {
             const size_t HW = (size_t)H * W;
             const size_t pid = (size_t)py * W + px;
             const float g0 = dL_dpix[pid], g1 = dL_dpix[HW + pid], g2 = dL_dpix[2 * HW + pid];
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
-            c1.z = __uint_as_float(ncon_c[pid]);
+            c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)lane);
         }
         pix[lane * 2] = c0;
         pix[lane * 2 + 1] = c1;
+        pix[128 + lane * 2] = c0;
+        pix[128 + lane * 2 + 1] = c1;
     }
 
     // record (p0,p1,p2) -> the loop's entry form + the row index 4 pair + quadrant
@@ -97,127 +101,139 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
     Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
-    uint32_t cur_row = 0, nxt_row = 0;  // row index of the lane's working entry / of its entry in `nxt`
+    // row indices of this lane's entries: row_new belongs to the chunk taken during the current round,
+    // row_old to the chunk before it (whose sums are parked during the current round)
+    uint32_t row_new = 0, row_old = 0;
     gather(lane, p0, p1, p2);
-    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by lane t at step t
+    convert(p0, p1, p2, nxt, row_new);  // chunk 0, taken by lane t at step t
     gather(64 + lane, p0, p1, p2);      // chunk 1 in flight during round 0
     __syncthreads();
 
-    bool has = false;   // the lane holds a live entry
-    bool pend = false;  // rowbuf[lane] holds a row not yet stored
     float acc[9];
 #pragma unroll
     for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
-    float T = 1.0f, Pfx = 0.f;    // state of the pixel currently at this lane
-    int pidx = (64 - lane) & 63;  // index of that pixel: (s - lane) mod 64
-    float4 pc0 = pix[pidx * 2], pc1 = pix[pidx * 2 + 1];
+    // byte offset into pix[] of the pixel at this lane: 32 * ((s - lane) mod 64), + 2048 within a round
+    uint32_t poff = (uint32_t)((64 - lane) & 63) * 32u;
+    const char* pixb = reinterpret_cast<const char*>(pix);
+    float4 pc0 = *reinterpret_cast<const float4*>(pixb + poff), pc1 = *reinterpret_cast<const float4*>(pixb + poff + 16);
+    // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
+    float T = 1.0f, Rem = pc0.w;
     const float il2 = 1.0f / LOG2E_F;
 
-    auto store_pending = [&]() {
-        if (pend) {
-            const float4 r0 = rowbuf[lane * 3], r1 = rowbuf[lane * 3 + 1], r2 = rowbuf[lane * 3 + 2];
-            const size_t row = __float_as_uint(r2.y);
-            qrows[row * 3] = make_float4(r0.x * il2, r0.y * il2, -0.5f * r0.z, -0.5f * r0.w);
-            qrows[row * 3 + 1] = make_float4(-0.5f * r1.x, r1.y, r1.z, r1.w);
-            qrows[row * 3 + 2] = make_float4(r2.x, 0.f, 0.f, 0.f);
-            qvalid[row] = 1;
-            pend = false;
-        }
+    // a finished entry's sums -> its row (the conic / mean combinations and the constant factors go
+    // in here, once per entry, instead of into the per-pair loop)
+    auto write_row = [&](size_t row, const float* a, float A2, float B2, float C2, float o) {
+        const float oa0 = o * a[0], oa1 = o * a[1];
+        const float m0 = 2.f * A2 * oa0 + B2 * oa1, m1 = 2.f * C2 * oa1 + B2 * oa0;
+        qrows[row * 3] = make_float4(m0 * il2, m1 * il2, (-0.5f * o) * a[2], (-0.5f * o) * a[3]);
+        qrows[row * 3 + 1] = make_float4((-0.5f * o) * a[4], a[5], a[6], a[7]);
+        qrows[row * 3 + 2] = make_float4(a[8], 0.f, 0.f, 0.f);
+        qvalid[row] = 1;
+    };
+    auto store_parked = [&](size_t row) {
+        const float4 r0 = rowbuf[lane * 4], r1 = rowbuf[lane * 4 + 1], r2 = rowbuf[lane * 4 + 2],
+                     r3 = rowbuf[lane * 4 + 3];
+        const float a[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+        write_row(row, a, r2.y, r2.z, r2.w, r3.x);
     };
 
+    // An entry k lives in its lane for the steps k .. k+63 and is parked at step k+64 when the lane
+    // takes entry k+64; the loop runs s = 0 .. m+62, so exactly the entries k <= m-2 get parked and
+    // entry m-1 is still in its lane's registers at the end.
     const int total = m + 63;
-    for (int s = 0; s < total; s++) {
-        const int t = s & 63;
-        if (t == 0 && s > 0) {
+    for (int s0 = 0; s0 < total; s0 += 64) {
+        if (s0 > 0) {
             // round start: every lane took its entry of the previous chunk out of `nxt` during the
-            // previous round.  Rows finished during that round -> HBM; the chunk that was in flight ->
-            // `nxt`; the chunk after it -> in flight.
+            // previous round.  Rows parked during that round (all 64 lanes, from round 2 on) -> HBM; the
+            // chunk that was in flight -> `nxt`; the chunk after it -> in flight.
             __syncthreads();
-            store_pending();
-            convert(p0, p1, p2, nxt, nxt_row);
-            gather(s + 64 + lane, p0, p1, p2);
+            if (s0 >= 128) store_parked(row_old);
+            row_old = row_new;
+            convert(p0, p1, p2, nxt, row_new);
+            gather(s0 + 64 + lane, p0, p1, p2);
+            poff -= 2048u;
             __syncthreads();
         }
-        const bool sw = lane == t;
-        if (sw && has) {
-            // this lane has seen all 64 pixels with its entry: park the row
-            rowbuf[t * 3] = make_float4(2.f * cur.A2 * acc[0] + cur.B2 * acc[1], 2.f * cur.C2 * acc[1] + cur.B2 * acc[0],
-                                        acc[2], acc[3]);
-            rowbuf[t * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            rowbuf[t * 3 + 2] = make_float4(acc[8], __uint_as_float(cur_row), 0.f, 0.f);
-            pend = true;
-        }
-        // ... and take the next entry (selects, no divergent block)
-        has = sw ? (s < m) : has;
-        cur.x = sw ? nxt.x : cur.x;
-        cur.y = sw ? nxt.y : cur.y;
-        cur.A2 = sw ? nxt.A2 : cur.A2;
-        cur.B2 = sw ? nxt.B2 : cur.B2;
-        cur.C2 = sw ? nxt.C2 : cur.C2;
-        cur.o = sw ? nxt.o : cur.o;
-        cur.r = sw ? nxt.r : cur.r;
-        cur.g = sw ? nxt.g : cur.g;
-        cur.b = sw ? nxt.b : cur.b;
-        cur_row = sw ? nxt_row : cur_row;
+        const int tend = min(64, total - s0);
+        auto step = [&](const int t) {
+            const uint32_t s = (uint32_t)(s0 + t);
+            if (lane == t) {
+                if (s0 > 0) {
+                    // this lane has seen all 64 pixels with its entry: park the sums
+                    rowbuf[t * 4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    rowbuf[t * 4 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    rowbuf[t * 4 + 2] = make_float4(acc[8], cur.A2, cur.B2, cur.C2);
+                    rowbuf[t * 4 + 3].x = cur.o;
+                }
+                // ... and take the next entry
+                cur = nxt;
 #pragma unroll
-        for (int c9 = 0; c9 < 9; c9++) acc[c9] = sw ? 0.f : acc[c9];
-        {
-            const float4 g = pc0;  // (g0, g1, g2, Gtot) of the pixel at this lane
-            const float pxf = pc1.x, pyf = pc1.y;
-            const uint32_t ncon = __float_as_uint(pc1.z);
-            const uint32_t k = (uint32_t)(s - pidx);  // compacted index of this lane's entry (pidx = s - k)
-            // next step's pixel constants, fetched now
-            pidx = (pidx + 1) & 63;
-            pc0 = pix[pidx * 2];
-            pc1 = pix[pidx * 2 + 1];
-            const float dx = cur.x - pxf, dy = cur.y - pyf;
-            const float power2 = cur.A2 * dx * dx + (cur.C2 * dy * dy + cur.B2 * dx * dy);
-            const float G = __builtin_amdgcn_exp2f(power2);
-            const float al = fminf(0.99f, cur.o * G);
-            // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
-            // power <= 0, the entry lies before the pixel's last contributor (k < ncon; also false for
-            // lanes without an entry: their k is out of range), and alpha >= 1/255 (which implies the
-            // forward's relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
-            const float a1 = (power2 <= 0.0f) ? al : 0.f;
-            const float a2 = (k < ncon) ? a1 : 0.f;
-            const bool valid = a2 >= (1.0f / 255.0f);
-            const float alpha = valid ? a2 : 0.f;
-            const float Gv = valid ? G : 0.f;
-            const float wgt = alpha * T;
-            const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
-            Pfx += cg * wgt;
-            const float one_m = 1.f - alpha;
-            const float dL_dalpha = T * cg - (g.w - Pfx) * __builtin_amdgcn_rcpf(one_m);
-            T *= one_m;
-            const float Gd = Gv * dL_dalpha;
-            const float tt = cur.o * Gd;  // G * dL/dG, dL/dG = opacity * dL/dalpha
-            const float tdx = tt * dx, tdy = tt * dy;
-            // sums (the conic / mean combinations and constant factors are applied when the row is stored):
-            //  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
-            //  6..8: w g_c = dL/dcolor
-            acc[0] += tdx;
-            acc[1] += tdy;
-            acc[2] += tdx * dx;
-            acc[3] += tdx * dy;
-            acc[4] += tdy * dy;
-            acc[5] += Gd;
-            acc[6] += wgt * g.x;
-            acc[7] += wgt * g.y;
-            acc[8] += wgt * g.z;
+                for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
+            }
+            {
+                const float4 g = pc0;  // (g0, g1, g2, Gtot) of the pixel at this lane
+                const float pxf = pc1.x, pyf = pc1.y;
+                const uint32_t lim = __float_as_uint(pc1.z);
+                // next step's pixel constants, fetched now
+                poff += 32u;
+                pc0 = *reinterpret_cast<const float4*>(pixb + poff);
+                pc1 = *reinterpret_cast<const float4*>(pixb + poff + 16);
+                const float dx = cur.x - pxf, dy = cur.y - pyf;
+                // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
+                const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float al = fminf(0.99f, cur.o * G);
+                // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
+                // power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that has no
+                // entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's
+                // relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
+                const float a1 = (power2 <= 0.0f) ? al : 0.f;
+                const float a2 = (s < lim) ? a1 : 0.f;
+                const bool valid = a2 >= (1.0f / 255.0f);
+                const float alpha = valid ? a2 : 0.f;
+                const float Gv = valid ? G : 0.f;
+                const float wgt = alpha * T;
+                const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
+                Rem = __builtin_fmaf(-cg, wgt, Rem);
+                const float one_m = 1.f - alpha;
+                const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
+                T *= one_m;
+                const float Gd = Gv * dL_dalpha;  // G dL/dalpha; times opacity it is G dL/dG (applied when parked)
+                const float tdx = Gd * dx, tdy = Gd * dy;
+                // sums:  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
+                //        6..8: w g_c = dL/dcolor
+                acc[0] += tdx;
+                acc[1] += tdy;
+                acc[2] += tdx * dx;
+                acc[3] += tdx * dy;
+                acc[4] += tdy * dy;
+                acc[5] += Gd;
+                acc[6] += wgt * g.x;
+                acc[7] += wgt * g.y;
+                acc[8] += wgt * g.z;
+            }
+            // the pixel moves on to the next entry = the next lane
+            T = wave_ror1(T);
+            Rem = wave_ror1(Rem);
+        };
+        // two steps per trip: the one-step-ahead pixel constants alternate between two register sets
+        int t = 0;
+        for (; t + 1 < tend; t += 2) {
+            step(t);
+            step(t + 1);
         }
-        // the pixel moves on to the next entry = the next lane
-        T = wave_ror1(T);
-        Pfx = wave_ror1(Pfx);
+        if (t < tend) step(t);
     }
     __syncthreads();
-    store_pending();
-    if (has) {
-        const size_t row = cur_row;
-        const float mx = 2.f * cur.A2 * acc[0] + cur.B2 * acc[1], my = 2.f * cur.C2 * acc[1] + cur.B2 * acc[0];
-        qrows[row * 3] = make_float4(mx * il2, my * il2, -0.5f * acc[2], -0.5f * acc[3]);
-        qrows[row * 3 + 1] = make_float4(-0.5f * acc[4], acc[5], acc[6], acc[7]);
-        qrows[row * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
-        qvalid[row] = 1;
+    {
+        const int last_round = (total - 1) >> 6, tend = ((total - 1) & 63) + 1;
+        // rows parked during the last round: the lanes that switched in it, entries of the chunk before
+        if (last_round >= 1 && lane < tend) store_parked(row_old);
+        // entry m-1 was never parked
+        if (lane == ((m - 1) & 63)) {
+            const size_t row = (((m - 1) >> 6) == last_round) ? row_new : row_old;
+            write_row(row, acc, cur.A2, cur.B2, cur.C2, cur.o);
+        }
     }
 }
 

@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                 if (MODE == 1) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xF, 0xF, false));
                 if (MODE == 2) a[i] = __builtin_amdgcn_exp2f(a[i]) ;
                 if (MODE == 3) a[i] = (a[i] > c) ? a[i] * m : a[i] + c;  // cmp + cndmask-ish
+                if (MODE == 4 && (i & 1) == 0) {  // packed fp32 fma: two floats per instruction
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 v = {a[i], a[i + 1]}, mm = {m, m}, cc = {c, c};
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(v), "v"(mm), "v"(cc));
+                    a[i] = v.x; a[i + 1] = v.y;
+                }
+                if (MODE == 5 && (i & 1) == 0) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 v = {a[i], a[i + 1]}, mm = {m, m};
+                    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(mm));
+                    a[i] = v.x; a[i + 1] = v.y;
+                }
             }
         }
     }
@@ -46,5 +58,7 @@ int main() {
     for (int b : {1, 2, 8}) { run<1>("dpp_add", b); }
     for (int b : {1, 2, 8}) { run<2>("exp2", b); }
     for (int b : {1, 2, 8}) { run<3>("cmp_sel", b); }
+    for (int b : {1, 2, 8}) { run<4>("pk_fma(x0.5 instr)", b); }
+    for (int b : {1, 2, 8}) { run<5>("pk_mul(x0.5 instr)", b); }
     return 0;
 }
