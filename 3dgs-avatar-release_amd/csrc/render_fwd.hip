@@ -39,6 +39,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     const int n = (int)(range.y - range.x);
     const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;  // this quadrant's slice of qlist / gradient rows
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 
     // A pixel is "alive" while T > 0.  The sign of T doubles as the done flag: when a contribution
     // would push T below 1e-4 the pixel is frozen as T := -T, which keeps final_T and makes every later
@@ -82,17 +84,19 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
         }
-        float4 na = srec[0], nb = srec[1], nc = srec[2];  // software-pipelined LDS reads
+        // The staged entries are read at a wave-uniform address.  Keeping that address in a VGPR the
+        // compiler cannot prove uniform (vzero) makes it one v_add per entry + immediate offsets; proven
+        // uniform, it is rebuilt from SGPRs with a v_mov per dword and a dozen scalar adds per entry, and
+        // the CU's single scalar unit becomes the bottleneck.
+        const char* sp = reinterpret_cast<const char*>(srec) + vzero;
         for (int j = 0; j < cnt; j++) {
-            const float4 a = na, b = nb, c = nc;
-            {
-                const int jn = min(j + 1, 63);
-                na = srec[jn * 3];
-                nb = srec[jn * 3 + 1];
-                nc = srec[jn * 3 + 2];
-            }
+            const float4 a = *reinterpret_cast<const float4*>(sp);
+            const float4 b = *reinterpret_cast<const float4*>(sp + 16);
+            const float4 c = *reinterpret_cast<const float4*>(sp + 32);
+            sp += 48;
             const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power2 = a.z * dx * dx + (b.x * dy * dy + a.w * dx * dy);
+            // A2 dx^2 + B2 dx dy + C2 dy^2, evaluated exactly as the backward does
+            const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
             const float al = fminf(0.99f, b.y * G);
             const float a1 = (power2 <= 0.0f) ? al : 0.f;
