@@ -49,7 +49,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ qrows, uint8_t* __restrict__ qvalid) {
     __shared__ float4 rowbuf[64 * 4];  // finished entries (nine sums + conic, opacity) waiting for the bulk store
-    __shared__ float4 pix[128 * 2];    // per-pixel constants, stored twice so a round's reads never wrap
+    // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
+    // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step), each stored twice
+    // so a round's reads never wrap:  g0, g1, g2, x, y, lim
+    __shared__ float pix[6][128];
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const int m = (int)qcount[tile * 4 + q];
     if (m == 0) return;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gtot0;  // Gtot of pixel `lane`
     {
         // (g0, g1, g2, Gtot) and (x, y, lim): pixel p meets compacted entry k at step s = k + p, and the
         // pair counts only while k < (its last contributor) <=> s < lim = ncon + p
@@ -73,10 +77,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
             c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)lane);
         }
-        pix[lane * 2] = c0;
-        pix[lane * 2 + 1] = c1;
-        pix[128 + lane * 2] = c0;
-        pix[128 + lane * 2 + 1] = c1;
+        pix[0][lane] = pix[0][64 + lane] = c0.x;
+        pix[1][lane] = pix[1][64 + lane] = c0.y;
+        pix[2][lane] = pix[2][64 + lane] = c0.z;
+        pix[3][lane] = pix[3][64 + lane] = c1.x;
+        pix[4][lane] = pix[4][64 + lane] = c1.y;
+        pix[5][lane] = pix[5][64 + lane] = c1.z;
+        gtot0 = c0.w;
     }
 
     // record (p0,p1,p2) -> the loop's entry form + the row index 4 pair + quadrant
@@ -112,12 +119,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     float acc[9];
 #pragma unroll
     for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
-    // byte offset into pix[] of the pixel at this lane: 32 * ((s - lane) mod 64), + 2048 within a round
-    uint32_t poff = (uint32_t)((64 - lane) & 63) * 32u;
-    const char* pixb = reinterpret_cast<const char*>(pix);
-    float4 pc0 = *reinterpret_cast<const float4*>(pixb + poff), pc1 = *reinterpret_cast<const float4*>(pixb + poff + 16);
+    // index into pix[c][] of the pixel at this lane: (s - lane) mod 64, + 64 within a round
+    uint32_t pidx = (uint32_t)((64 - lane) & 63);
+    float pc[6];
+#pragma unroll
+    for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
-    float T = 1.0f, Rem = pc0.w;
+    // (pixel p starts at lane (64 - p) mod 64; fetch its Gtot from the lane that loaded it)
+    float T = 1.0f, Rem = __shfl(gtot0, (int)pidx, 64);
     const float il2 = 1.0f / LOG2E_F;
 
     // a finished entry's sums -> its row (the conic / mean combinations and the constant factors go
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             row_old = row_new;
             convert(p0, p1, p2, nxt, row_new);
             gather(s0 + 64 + lane, p0, p1, p2);
-            poff -= 2048u;
+            pidx -= 64u;
             __syncthreads();
         }
         const int tend = min(64, total - s0);
@@ -171,13 +180,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                 for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
             }
             {
-                const float4 g = pc0;  // (g0, g1, g2, Gtot) of the pixel at this lane
-                const float pxf = pc1.x, pyf = pc1.y;
-                const uint32_t lim = __float_as_uint(pc1.z);
+                const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
+                const float pxf = pc[3], pyf = pc[4];
+                const uint32_t lim = __float_as_uint(pc[5]);
                 // next step's pixel constants, fetched now
-                poff += 32u;
-                pc0 = *reinterpret_cast<const float4*>(pixb + poff);
-                pc1 = *reinterpret_cast<const float4*>(pixb + poff + 16);
+                pidx += 1u;
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
                 const float dx = cur.x - pxf, dy = cur.y - pyf;
                 // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
                 const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);

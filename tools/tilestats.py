@@ -21,3 +21,18 @@ print("radii mean %.1f max %d; tiles_touched mean %.1f" % (st["radii"].mean(), s
 rec = st["geom"]["rec"]; print("opacity mean %.3f median %.3f frac<1/255 %.4f" % (rec[:,5].mean(), np.median(rec[:,5]), (rec[:,5]<1/255).mean()))
 qc = st["image"]["qcount"].astype(np.int64)
 print("compacted entries up to last contributor: sum %d (%.3f D), per quadrant mean %.0f max %d; steps incl. fill %d" % (qc.sum(), qc.sum()/st["D"], qc.mean(), qc.max(), (qc + 63 * (qc > 0)).sum()))
+# list scheduling of the per-quadrant backward work (steps = m + 63) on 1024 SIMDs x K resident waves
+steps = (qc + 63 * (qc > 0)).astype(np.int64)
+steps = steps[steps > 0]
+srt = np.sort(steps)[::-1]
+print("quadrants with work %d; steps: max %d p99 %d p90 %d p50 %d; total %d" % (len(srt), srt[0], np.percentile(srt, 99), np.percentile(srt, 90), np.percentile(srt, 50), srt.sum()))
+import heapq
+for slots in (1024, 1024 * 5):
+    h = [0] * slots
+    heapq.heapify(h)
+    for w in srt:
+        t = heapq.heappop(h)
+        heapq.heappush(h, t + int(w))
+    mk = max(h)
+    print("slots %d: makespan %d steps vs ideal %.0f (critical path %d)" % (slots, mk, srt.sum() / slots, srt[0]))
+np.save("gpurun_out/qcount_config3.npy", qc)
