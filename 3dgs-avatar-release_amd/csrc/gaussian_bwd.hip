@@ -49,7 +49,20 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
         v += dpp_get<0x140, 0xF>(v);  // row_mirror: lane <-> 15 - lane inside the row of 16
         s[c] = v;
     }
+    // The rows hold raw sums over pixels: (t dx, t dy, t dx^2, t dx dy, t dy^2, G dL/dalpha, w g_rgb) with
+    // t = G dL/dalpha.  Apply what is constant per Gaussian: opacity (dL/dG = opacity dL/dalpha), the
+    // conic combination giving dL/dmean2D (in the log2 domain the tile kernels work in), and the -1/2 of
+    // dL/dconic.
     if (in && j < 3) {
+        const float4 r0 = rec[(size_t)i * 3], r1 = rec[(size_t)i * 3 + 1];
+        const float A2 = (-0.5f * LOG2E_F) * r0.z, B2 = -LOG2E_F * r0.w, C2 = (-0.5f * LOG2E_F) * r1.x, op = r1.y;
+        const float il2 = 1.0f / LOG2E_F;
+        const float oa0 = op * s[0], oa1 = op * s[1];
+        s[0] = (2.f * A2 * oa0 + B2 * oa1) * il2;
+        s[1] = (2.f * C2 * oa1 + B2 * oa0) * il2;
+        s[2] *= -0.5f * op;
+        s[3] *= -0.5f * op;
+        s[4] *= -0.5f * op;
         const float4 o = (j == 0) ? make_float4(s[0], s[1], s[2], s[3])
                                   : (j == 1) ? make_float4(s[4], s[5], s[6], s[7]) : make_float4(s[8], 0.f, 0.f, 0.f);
         sums[(size_t)i * 3 + j] = o;

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ qrows, uint8_t* __restrict__ qvalid) {
-    __shared__ float4 rowbuf[64 * 4];  // finished entries (nine sums + conic, opacity) waiting for the bulk store
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step), each stored twice
     // so a round's reads never wrap:  g0, g1, g2, x, y, lim
@@ -108,11 +107,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
     Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
-    // row indices of this lane's entries: row_new belongs to the chunk taken during the current round,
-    // row_old to the chunk before it (whose sums are parked during the current round)
-    uint32_t row_new = 0, row_old = 0;
+    uint32_t cur_row = 0, nxt_row = 0;  // gradient row (4 pair + quadrant) of the working entry / of `nxt`
     gather(lane, p0, p1, p2);
-    convert(p0, p1, p2, nxt, row_new);  // chunk 0, taken by lane t at step t
+    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by lane t at step t
     gather(64 + lane, p0, p1, p2);      // chunk 1 in flight during round 0
     __syncthreads();
 
@@ -127,55 +124,38 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
     // (pixel p starts at lane (64 - p) mod 64; fetch its Gtot from the lane that loaded it)
     float T = 1.0f, Rem = __shfl(gtot0, (int)pidx, 64);
-    const float il2 = 1.0f / LOG2E_F;
 
-    // a finished entry's sums -> its row (the conic / mean combinations and the constant factors go
-    // in here, once per entry, instead of into the per-pair loop)
-    auto write_row = [&](size_t row, const float* a, float A2, float B2, float C2, float o) {
-        const float oa0 = o * a[0], oa1 = o * a[1];
-        const float m0 = 2.f * A2 * oa0 + B2 * oa1, m1 = 2.f * C2 * oa1 + B2 * oa0;
-        qrows[row * 3] = make_float4(m0 * il2, m1 * il2, (-0.5f * o) * a[2], (-0.5f * o) * a[3]);
-        qrows[row * 3 + 1] = make_float4((-0.5f * o) * a[4], a[5], a[6], a[7]);
-        qrows[row * 3 + 2] = make_float4(a[8], 0.f, 0.f, 0.f);
+    // A finished entry's nine RAW sums go straight to its row in HBM, stored by the one lane that owns
+    // them (global stores count on vmcnt, so they never hold up the LDS waits of the step loop).  What
+    // is constant per Gaussian -- opacity, the conic combination of the two first moments, the -1/2 and
+    // 1/log2(e) factors -- is applied once per Gaussian by segment_reduce_kernel.
+    auto write_row = [&](size_t row) {
+        qrows[row * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        qrows[row * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        reinterpret_cast<float*>(qrows + row * 3 + 2)[0] = acc[8];
         qvalid[row] = 1;
     };
-    auto store_parked = [&](size_t row) {
-        const float4 r0 = rowbuf[lane * 4], r1 = rowbuf[lane * 4 + 1], r2 = rowbuf[lane * 4 + 2],
-                     r3 = rowbuf[lane * 4 + 3];
-        const float a[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-        write_row(row, a, r2.y, r2.z, r2.w, r3.x);
-    };
 
-    // An entry k lives in its lane for the steps k .. k+63 and is parked at step k+64 when the lane
-    // takes entry k+64; the loop runs s = 0 .. m+62, so exactly the entries k <= m-2 get parked and
+    // An entry k lives in its lane for the steps k .. k+63 and is stored at step k+64 when the lane
+    // takes entry k+64; the loop runs s = 0 .. m+62, so exactly the entries k <= m-2 get stored there and
     // entry m-1 is still in its lane's registers at the end.
     const int total = m + 63;
     for (int s0 = 0; s0 < total; s0 += 64) {
         if (s0 > 0) {
             // round start: every lane took its entry of the previous chunk out of `nxt` during the
-            // previous round.  Rows parked during that round (all 64 lanes, from round 2 on) -> HBM; the
-            // chunk that was in flight -> `nxt`; the chunk after it -> in flight.
-            __syncthreads();
-            if (s0 >= 128) store_parked(row_old);
-            row_old = row_new;
-            convert(p0, p1, p2, nxt, row_new);
+            // previous round.  The chunk that was in flight -> `nxt`; the chunk after it -> in flight.
+            convert(p0, p1, p2, nxt, nxt_row);
             gather(s0 + 64 + lane, p0, p1, p2);
             pidx -= 64u;
-            __syncthreads();
         }
         const int tend = min(64, total - s0);
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
             if (lane == t) {
-                if (s0 > 0) {
-                    // this lane has seen all 64 pixels with its entry: park the sums
-                    rowbuf[t * 4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    rowbuf[t * 4 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                    rowbuf[t * 4 + 2] = make_float4(acc[8], cur.A2, cur.B2, cur.C2);
-                    rowbuf[t * 4 + 3].x = cur.o;
-                }
+                if (s0 > 0) write_row(cur_row);  // this lane has seen all 64 pixels with its entry
                 // ... and take the next entry
                 cur = nxt;
+                cur_row = nxt_row;
 #pragma unroll
                 for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
             }
@@ -233,17 +213,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         }
         if (t < tend) step(t);
     }
-    __syncthreads();
-    {
-        const int last_round = (total - 1) >> 6, tend = ((total - 1) & 63) + 1;
-        // rows parked during the last round: the lanes that switched in it, entries of the chunk before
-        if (last_round >= 1 && lane < tend) store_parked(row_old);
-        // entry m-1 was never parked
-        if (lane == ((m - 1) & 63)) {
-            const size_t row = (((m - 1) >> 6) == last_round) ? row_new : row_old;
-            write_row(row, acc, cur.A2, cur.B2, cur.C2, cur.o);
-        }
-    }
+    // entry m-1 was never stored
+    if (lane == ((m - 1) & 63)) write_row(cur_row);
 }
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
