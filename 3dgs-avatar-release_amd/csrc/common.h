@@ -18,10 +18,11 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 #define SORT_ITEMS 4096          // elements per radix-sort block (256 threads x 16)
 #define SORT_SMALL_N (1 << 20)   // sorts up to this size use 1024-element blocks instead
-// number of [256]-row table columns a sort of n elements needs (either block size) + 4 rows of totals
+#define SORT_TOTALS_REPL 16       // replicas of the per-pass digit totals (spreads the atomic adds)
+// words of the radix sort's tables for n elements (either block size): [256][nblk] + 4 passes of totals
 static inline size_t sort_table_words(size_t n) {
     const size_t items = n <= (size_t)SORT_SMALL_N ? 1024 : SORT_ITEMS;
-    return (size_t)256 * ((n + items - 1) / items + 4);
+    return (size_t)256 * ((n + items - 1) / items + 4 * SORT_TOTALS_REPL);
 }
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 

@@ -7,6 +7,7 @@
 
 #define RS_THREADS 256
 #define RS_ROUNDS_BIG (SORT_ITEMS / RS_THREADS)  // 16 keys per thread: large sorts
+#define RS_REPL SORT_TOTALS_REPL
 #define RS_ROUNDS_SMALL 4                      // 4 keys per thread: small sorts finish sooner on more CUs
 
 // wave-level digit match: lanes holding the same 8-bit digit find each other with 8 ballots.
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     }
     __syncthreads();
     hist[(size_t)tid * nblk + blockIdx.x] = h[tid];
-    if (h[tid]) atomicAdd(&totals[tid], h[tid]);
+    // digit totals, spread over RS_REPL replicas: hundreds of blocks adding to the same 256 words
+    // serialise in the L2 atomic units (that, not the counting, dominated this kernel)
+    if (h[tid]) atomicAdd(&totals[(blockIdx.x % RS_REPL) * 256 + tid], h[tid]);
 }
 
 // Exclusive scan of the digit-major [256][nblk] table, one workgroup per digit: block d adds the
@@ -58,7 +61,9 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ his
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int d = blockIdx.x;
-    uint32_t v = (tid < d) ? totals[tid] : 0u;
+    uint32_t v = 0u;
+    if (tid < d)
+        for (int r = 0; r < RS_REPL; r++) v += totals[r * 256 + tid];
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
     if (lane == 0) ws[wid] = v;
@@ -194,15 +199,15 @@ static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
     const int dbits = 8;  // (an equal 6 + 6 split of 12 tile bits measured no faster than 8 + 4)
     // per-pass digit totals live behind the [256][nblk] table (the layouts reserve room for them)
     uint32_t* totals = hist + (size_t)256 * nblk;
-    hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
+    hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * RS_REPL * 256 * 4, s);
     if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
         const int shift = dbits * p;
         hipLaunchKernelGGL(rs_hist_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, dbits, hist, nblk,
-                           totals + 256 * p);
+                           totals + RS_REPL * 256 * p);
         GS_LAUNCH_CHECK("sort.hist", debug, s);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << dbits), dim3(256), 0, s, hist, nblk, totals + 256 * p);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << dbits), dim3(256), 0, s, hist, nblk, totals + RS_REPL * 256 * p);
         GS_LAUNCH_CHECK("sort.scan", debug, s);
         hipLaunchKernelGGL(rs_scatter_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift,
                            dbits, hist, nblk);
