@@ -24,32 +24,37 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
     return peers;
 }
 
-// Per-block digit histogram.  Equal digits inside a wave are matched first and counted by one lane,
-// so runs of identical keys (tile ids in emission order, depth exponents) do not serialise on one
-// LDS address.
+// Per-block digit histogram: LDS atomic adds into a histogram private to each wave (the LDS unit
+// resolves equal addresses inside one instruction at a word per clock, which beats matching equal
+// digits with ballots first), summed over the four waves at the end.
 template <int RS_ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                              int dbits, uint32_t* __restrict__ hist, int nblk,
                                                              uint32_t* __restrict__ totals) {
-    __shared__ uint32_t h[256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    h[tid] = 0;
+    __shared__ uint32_t h[4][256];
+    const int tid = threadIdx.x, wid = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) h[w][tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_ROUNDS * RS_THREADS);
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll 4
+    const uint32_t dmask = (1u << dbits) - 1u;
+    uint32_t key[RS_ROUNDS];
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t i = base + r * RS_THREADS + tid;
-        const bool valid = i < n;
-        const uint32_t digit = valid ? ((keys[i] >> shift) & ((1u << dbits) - 1u)) : 0u;
-        const unsigned long long peers = match_digit(digit, valid, dbits);
-        if (valid && (peers & lt_mask) == 0ull) atomicAdd(&h[digit], (uint32_t)__popcll(peers));
+        key[r] = i < n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t i = base + r * RS_THREADS + tid;
+        if (i < n) atomicAdd(&h[wid][(key[r] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    hist[(size_t)tid * nblk + blockIdx.x] = h[tid];
+    const uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    hist[(size_t)tid * nblk + blockIdx.x] = c;
     // digit totals, spread over RS_REPL replicas: hundreds of blocks adding to the same 256 words
     // serialise in the L2 atomic units (that, not the counting, dominated this kernel)
-    if (h[tid]) atomicAdd(&totals[(blockIdx.x % RS_REPL) * 256 + tid], h[tid]);
+    if (c) atomicAdd(&totals[(blockIdx.x % RS_REPL) * 256 + tid], c);
 }
 
 // Exclusive scan of the digit-major [256][nblk] table, one workgroup per digit: block d adds the
