@@ -258,18 +258,18 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         ql.qlist = (uint32_t*)(b + B.qlist);
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
-        uint8_t* qvalid = (uint8_t*)scratch + scratch_rows_bytes(D);
+        uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         {
-            hipError_t e = hipMemsetAsync(qvalid, 0, (size_t)D * 4, s);  // 0 = "row not written"
-            if (e != hipSuccess) { gs_set_error((int)e, "qvalid.memset"); return GS_E_HIP; }
+            hipError_t e = hipMemsetAsync(q8, 0xFF, (size_t)D * 16, s);  // ROW_UNWRITTEN everywhere
+            if (e != hipSuccess) { gs_set_error((int)e, "q8.memset"); return GS_E_HIP; }
         }
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
-                                    out_color, dL_dpix, (float*)scratch, qvalid, s); }
+                                    out_color, dL_dpix, (float*)scratch, q8, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -278,7 +278,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
     }
     StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
-                                    (const uint32_t*)(g + L.clamped), (const uint8_t*)scratch + scratch_rows_bytes(D),
+                                    (const uint32_t*)(g + L.clamped), (const uint32_t*)((const char*)scratch + scratch_rows_bytes(D)),
                                     (const float*)scratch,
                                     (float*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D)), *gr, s);
 }

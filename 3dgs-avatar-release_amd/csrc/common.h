@@ -155,14 +155,16 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
                           const QuadLists& ql, hipStream_t s);
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           uint8_t* qvalid, hipStream_t s);
+                           uint32_t* q8, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const uint8_t* qvalid, const float* qrows, float* sums,
+                             const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s);
-// backward scratch: [4 D rows x 48 B: gradient row of (pair, quadrant) at index 4 pair + quadrant, pairs in
-// emission order | 4 D bytes: row-written flags | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
-static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * REC_F * 4, 256); }
-static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4, 256); }
+// backward scratch: [4 D rows x 32 B: sums 0..7 of (pair, quadrant) at index 4 pair + quadrant, pairs in
+// emission order (one 32-byte sector per row) | 4 D words: sum 8 of the row, or ROW_UNWRITTEN (the caller
+// fills the array with 0xFF bytes) | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
+#define ROW_UNWRITTEN 0xFFFFFFFFu  // a NaN pattern no arithmetic produces
+static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 32, 256); }
+static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 4, 256); }
 static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }
 static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {
     return scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);

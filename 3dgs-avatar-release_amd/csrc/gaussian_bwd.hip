@@ -9,11 +9,11 @@
 
 // Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous
 // span of pairs; each pair has four row slots (one per 8x8 quadrant of the tile), of which the
-// backward tile kernel wrote those flagged in qvalid; fold with four DPP adds.  sums[i] = 12 floats.
+// backward tile kernel wrote those whose ninth sum is not ROW_UNWRITTEN; fold with four DPP adds.  sums[i] = 12 floats.
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ tiles,
-                                                             const uint32_t* __restrict__ qvalid,
+                                                             const uint4* __restrict__ q8,
                                                              const float4* __restrict__ qrows,
                                                              float4* __restrict__ sums) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,17 +26,17 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
         const uint32_t tt = tiles[i];
         for (uint32_t k = j; k < tt; k += 16) {
-            const uint32_t vm = qvalid[off + k];  // four flag bytes of this pair
+            const uint4 w8 = q8[off + k];  // ninth sum of the pair's four rows, or ROW_UNWRITTEN
+            const uint32_t e8[4] = {w8.x, w8.y, w8.z, w8.w};
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
-                if (!((vm >> (8 * qq)) & 0xFFu)) continue;
+                if (e8[qq] == ROW_UNWRITTEN) continue;
                 const size_t row = (size_t)(off + k) * 4 + qq;
-                const float4 e0 = qrows[row * 3];
-                const float4 e1 = qrows[row * 3 + 1];
-                const float e2 = qrows[row * 3 + 2].x;
+                const float4 e0 = qrows[row * 2];
+                const float4 e1 = qrows[row * 2 + 1];
                 s[0] += e0.x; s[1] += e0.y; s[2] += e0.z; s[3] += e0.w;
                 s[4] += e1.x; s[5] += e1.y; s[6] += e1.z; s[7] += e1.w;
-                s[8] += e2;
+                s[8] += __uint_as_float(e8[qq]);
             }
         }
     }
@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 }
 
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
-                             const uint32_t* clamped, const uint8_t* qvalid, const float* qrows, float* sums,
+                             const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
     hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)(((size_t)a.P * 16 + 255) / 256)), dim3(256), 0, s, a.P, radii,
-                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint32_t*>(qvalid),
+                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint4*>(q8),
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
     const size_t lds = a.shs ? (size_t)256 * ((3 * a.M) | 1) * sizeof(float) : 0;

@@ -24,9 +24,10 @@
 //        dL/dalpha_i = T_i (c_i . g) - (Gtot - Pfx_i) / (1 - alpha_i)
 //    which is the reference's back-to-front recurrence (accum_rec / T division) rewritten so that T is
 //    rebuilt by the same multiplications the forward did.
-//  * Output: the 48-byte gradient row of (pair, quadrant) at qrows[4 pair + quadrant], pairs in EMISSION
-//    order (Gaussian-major), so the per-Gaussian kernel reads one contiguous span per Gaussian; a byte
-//    per row (qvalid, cleared by the caller) says which rows were written.
+//  * Output: the nine raw sums of (pair, quadrant) at row 4 pair + quadrant, pairs in EMISSION order
+//    (Gaussian-major), so the per-Gaussian kernel reads one contiguous span per Gaussian: eight sums in
+//    a 32-byte row, the ninth in a dense word array the caller pre-fills with ROW_UNWRITTEN, so it also
+//    tells which rows were written.
 #include "common.h"
 #include "blend.h"
 
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const uint32_t* __restrict__ qcount,
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
-                                                        float4* __restrict__ qrows, uint8_t* __restrict__ qvalid) {
+                                                        float4* __restrict__ qrows, uint32_t* __restrict__ q8) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step), each stored twice
     // so a round's reads never wrap:  g0, g1, g2, x, y, lim
@@ -130,10 +131,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // is constant per Gaussian -- opacity, the conic combination of the two first moments, the -1/2 and
     // 1/log2(e) factors -- is applied once per Gaussian by segment_reduce_kernel.
     auto write_row = [&](size_t row) {
-        qrows[row * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        qrows[row * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        reinterpret_cast<float*>(qrows + row * 3 + 2)[0] = acc[8];
-        qvalid[row] = 1;
+        qrows[row * 2] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        qrows[row * 2 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        q8[row] = __float_as_uint(acc[8]);  // the ninth sum doubles as the "row written" mark
     };
 
     // An entry k lives in its lane for the steps k .. k+63 and is stored at step k+64 when the lane
@@ -219,11 +219,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           uint8_t* qvalid, hipStream_t s) {
+                           uint32_t* q8, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                        reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
-                       out_color, dL_dpix, reinterpret_cast<float4*>(qrows), qvalid);
+                       out_color, dL_dpix, reinterpret_cast<float4*>(qrows), q8);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }
