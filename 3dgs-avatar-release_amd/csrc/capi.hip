@@ -302,6 +302,19 @@ int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, s
     return launch_knn(P, points, mean_d2, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int gs_l1_loss_workspace_bytes(int64_t n, size_t* out) {
+    if (!out || n < 0) return GS_E_BAD_ARG;
+    *out = l1_ws_bytes(n);
+    return GS_OK;
+}
+int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace, size_t workspace_bytes,
+               void* stream) {
+    if (n <= 0 || !x || !y || !loss || !dL_dx || !workspace) return GS_E_BAD_ARG;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)dL_dx) & 15u) return GS_E_BAD_ARG;  // float4 accesses
+    if (workspace_bytes < l1_ws_bytes(n)) return GS_E_WORKSPACE;
+    return launch_l1_loss(x, y, n, loss, dL_dx, (float*)workspace, (hipStream_t)stream);
+}
+
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {
     if (!geom || !out || P < 0) return GS_E_BAD_ARG;
     const GeomLayout L = geom_layout(P);

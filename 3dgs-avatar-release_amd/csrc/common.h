@@ -142,6 +142,10 @@ int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint3
                 uint32_t* vals, int P, int gx, int debug, hipStream_t s);
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
 
+// fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
+size_t l1_ws_bytes(int64_t n);
+int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
+
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
                       hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)

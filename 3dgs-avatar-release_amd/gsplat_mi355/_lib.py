@@ -28,7 +28,8 @@ class GsGrads(ctypes.Structure):
 EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_scratch_bytes",
            "gs_forward_preprocess", "gs_forward_render", "gs_forward_shared", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
-           "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect"]
+           "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
+           "gs_l1_loss_workspace_bytes", "gs_l1_loss"]
 
 _lock = threading.Lock()
 _lib = None
@@ -62,6 +63,8 @@ def load():
         L.gs_mark_visible.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.knn_workspace_bytes.argtypes = [c_int32, POINTER(c_size_t)]
         L.knn_dist2.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.gs_l1_loss_workspace_bytes.argtypes = [c_int64, POINTER(c_size_t)]
+        L.gs_l1_loss.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.gs_geom_field.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]

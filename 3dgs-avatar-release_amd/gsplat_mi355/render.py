@@ -4,11 +4,14 @@ the part of the train step that touches the rasterizer (train.py:114-124,143-153
 The deformer / texture modules upstream of the seam are out of scope: the Gaussian
 state arrives post-activation as a `GaussianCloud`.
 """
+import ctypes
 import math
 
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+from . import _lib
 
 
 class Pipe(object):
@@ -78,8 +81,42 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
                          visibility_filter=radii > 0, radii=radii, opacity_render=opacity_image)
 
 
+class _L1Loss(torch.autograd.Function):
+    """mean |x - y| with d/dx = sign(x - y) / n written by the same HIP pass (gs_l1_loss)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        L = _lib.load()
+        n = x.numel()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        ws = torch.empty(_lib.nbytes(L.gs_l1_loss_workspace_bytes, n), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            sptr = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(L.gs_l1_loss(n, x.data_ptr(), y.data_ptr(), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), sptr))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        gx = grad * g
+        return (gx if ctx.needs_input_grad[0] else None), (-gx if ctx.needs_input_grad[1] else None)
+
+
 def l1_loss(network_output, gt):
-    return torch.abs(network_output - gt).mean()  # utils/loss_utils.py:21-22
+    """torch.abs(network_output - gt).mean() of utils/loss_utils.py:21-22 as ONE fused HIP pass
+    (SURVEY.md 8f row N2).  Device fp32 tensors only: there is no CPU path."""
+    if not (network_output.is_cuda and gt.is_cuda):
+        raise RuntimeError("l1_loss: both tensors must live on the GPU (the fused HIP kernel has no CPU fallback)")
+    if network_output.dtype != torch.float32 or gt.dtype != torch.float32:
+        raise TypeError("l1_loss: fp32 tensors expected")
+    if network_output.numel() == 0:
+        raise ValueError("l1_loss: empty input")
+    if network_output.shape != gt.shape:
+        network_output, gt = torch.broadcast_tensors(network_output, gt)
+    return _L1Loss.apply(network_output.contiguous(), gt.contiguous())
 
 
 class DensifyStats(object):

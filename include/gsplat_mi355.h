@@ -128,6 +128,14 @@ int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
 int knn_workspace_bytes(int32_t P, size_t* out);
 int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image-side L1 loss: the reference computes
+ * torch.abs(network_output - gt).mean() (utils/loss_utils.py:21-22, called at train.py:121) and lets
+ * autograd derive d(loss)/d(network_output).  One call here: loss[0] = mean |x - y| and
+ * dL_dx[i] = sign(x[i] - y[i]) / n, for n fp32 elements (pointers 16-byte aligned); deterministic. ---- */
+int gs_l1_loss_workspace_bytes(int64_t n, size_t* out);
+int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace,
+               size_t workspace_bytes, void* stream);
+
 /* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
  *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
  *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))

@@ -616,6 +616,20 @@ int or_dist2(int P, const float* pts, float* out) {
     return 0;
 }
 
+/* N2: image L1 loss of utils/loss_utils.py:21-22, torch.abs(network_output - gt).mean(), and the
+ * gradient autograd derives for it: sign(x - y) / n (sign(0) = 0; 1/n rounded to fp32 as torch's mean
+ * backward does).  The sum is kept in double (the order of a float reduction is unspecified). */
+double or_l1_loss(long long n, const float* x, const float* y, float* grad) {
+    double acc = 0.0;
+    const float inv_n = 1.0f / (float)n;
+    for (long long i = 0; i < n; i++) {
+        const float d = x[i] - y[i];
+        acc += fabs((double)d);
+        if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    return acc / (double)n;
+}
+
 void or_set_num_threads(int n) {
 #ifdef _OPENMP
     extern void omp_set_num_threads(int);

@@ -210,6 +210,17 @@ def dist2(points):
     return out
 
 
+def l1_loss(x, y):
+    """N2 restatement: (mean |x - y| as float64, d/dx = sign(x - y) / n as fp32)."""
+    a, b = _f32(x).reshape(-1), _f32(y).reshape(-1)
+    assert a.size == b.size and a.size > 0
+    g = np.zeros(a.size, np.float32)
+    fn = lib().or_l1_loss
+    fn.restype = ctypes.c_double
+    v = fn(ctypes.c_longlong(a.size), _ptr(a), _ptr(b), _ptr(g))
+    return float(v), g.reshape(np.shape(x))
+
+
 def set_num_threads(n):
     lib().or_set_num_threads(c_int(int(n)))
 

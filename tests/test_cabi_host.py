@@ -39,7 +39,7 @@ def test_size_functions_and_status_strings(lib):
     b = lib.nbytes(L.gs_binning_bytes, 5_000_000, 1024, 1024)
     assert b >= 5_000_000 * 16
     s = lib.nbytes(L.gs_backward_scratch_bytes, 5_000_000, 200000, 1024, 1024)
-    assert s >= 5_000_000 * 4 * 48
+    assert s >= 5_000_000 * 4 * 36  # nine fp32 sums per (pair, quadrant) row
     assert lib.nbytes(L.knn_workspace_bytes, 50000) > 50000 * 16
     for code in (0, -1, -2, -3, -4, -5):
         assert len(L.gs_status_string(code)) > 0

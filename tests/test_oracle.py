@@ -255,3 +255,25 @@ def test_dist2_brute_force_vs_kdtree(oracle):
     # duplicated points: the twin is at distance 0 (self excluded by index only)
     pts2 = np.concatenate([pts[:10], pts[:10], pts[:10], pts[:10]])
     assert (oracle.dist2(pts2) == 0).all()
+
+
+def test_l1_loss_closed_forms(oracle):
+    """N2 oracle (utils/loss_utils.py:21-22): mean |x - y| and its autograd gradient sign(x - y) / n."""
+    x = np.array([[0.5, 0.25, 1.0], [0.0, 0.75, 0.125]], np.float32)
+    y = np.array([[0.25, 0.25, 0.0], [0.5, 0.5, 0.125]], np.float32)
+    v, g = oracle.l1_loss(x, y)
+    assert v == pytest.approx((0.25 + 0 + 1.0 + 0.5 + 0.25 + 0) / 6, rel=1e-12)
+    inv = np.float32(1.0) / np.float32(6)
+    assert np.array_equal(g, np.array([[inv, 0, inv], [-inv, inv, 0]], np.float32))
+    # against torch's own formula and autograd on the CPU
+    import torch
+    rng = np.random.default_rng(3)
+    a = rng.random((3, 37, 41), dtype=np.float32)
+    b = rng.random((3, 37, 41), dtype=np.float32)
+    b[0, :5] = a[0, :5]  # exact zeros exercise sign(0) = 0
+    ta = torch.from_numpy(a).requires_grad_(True)
+    loss = torch.abs(ta - torch.from_numpy(b)).mean()
+    loss.backward()
+    v, g = oracle.l1_loss(a, b)
+    assert v == pytest.approx(float(loss), rel=1e-6)
+    assert np.array_equal(g, ta.grad.numpy())
