@@ -117,64 +117,78 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
 // Emission of the (tile id, Gaussian index) pairs in depth-rank order, tiles y-outer / x-inner
 // (the upstream duplicateWithKeys order).  Also records each Gaussian's first pair index in its
 // splat record (slot 9): the backward pass addresses its per-pair gradient rows through it.
-// Wave-cooperative: a wave owns 64 consecutive ranks, i.e. one CONTIGUOUS span of output pairs; its
-// lanes walk that span 64 pairs at a time (fully coalesced stores) and find each pair's owner with a
-// 6-step binary search over the lanes' first-pair offsets (lane shuffles).
+//
+// Partitioned by OUTPUT, not by Gaussian: the nearest Gaussians come first in depth order and cover
+// hundreds of tiles each, so a wave that owns 64 consecutive ranks can have 100x the pairs of
+// another.  A workgroup owns EMIT_CHUNK consecutive pairs; emit_owner_kernel has recorded which rank
+// owns the first pair of every chunk, so the group stages the (at most EMIT_CHUNK + 1) ranks that
+// overlap its chunk in LDS and every pair finds its owner with a binary search over their offsets.
+// Stores are fully coalesced.
+__global__ __launch_bounds__(256) void emit_owner_kernel(const uint32_t* __restrict__ tt_rank,
+                                                         const uint32_t* __restrict__ offs, int P, uint32_t D,
+                                                         uint32_t nchunks, uint32_t* __restrict__ owner) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t tt = tt_rank[r];
+    if (!tt) return;
+    const uint32_t off = offs[r], last = off + tt - 1;
+    for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; c <= last / EMIT_CHUNK; c++) owner[c] = (uint32_t)r;
+    if (last == D - 1) owner[nchunks] = (uint32_t)r;  // the rank that owns the last pair
+}
+
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                   const uint32_t* __restrict__ tt_rank,
-                                                   const uint32_t* __restrict__ offs, float* __restrict__ rec,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int P,
-                                                   int gx) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;  // rank handled by this lane (a wave = 64 ranks)
-    const int lane = threadIdx.x & 63;
-    uint32_t tt = 0, off = 0xFFFFFFFFu, idx = 0, rmin = 0, rsz = 0;
-    if (r < P) {
-        tt = tt_rank[r];
-        off = offs[r];
-        idx = sorted_idx[r];
-        if (tt) {
-            float* R = rec + (size_t)idx * REC_F;
-            R[9] = __uint_as_float(off);
-            rmin = __float_as_uint(R[10]);
-            rsz = __float_as_uint(R[11]);
-        }
+                                                   const uint32_t* __restrict__ offs,
+                                                   const uint32_t* __restrict__ owner, float* __restrict__ rec,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                   uint32_t D, uint32_t nchunks, int gx) {
+    __shared__ uint32_t s_off[EMIT_CHUNK + 1], s_idx[EMIT_CHUNK + 1], s_rmin[EMIT_CHUNK + 1], s_rsz[EMIT_CHUNK + 1];
+    const uint32_t c = blockIdx.x;
+    const uint32_t o0 = c * EMIT_CHUNK, o1 = min(D, o0 + EMIT_CHUNK);
+    const uint32_t r0 = owner[c], r1 = owner[c + 1 < nchunks ? c + 1 : nchunks];
+    // every rank in [r0, r1] has at least one pair (Gaussians without tiles sort behind all others), so
+    // they are at most EMIT_CHUNK + 1
+    const int cnt = (int)min(r1 - r0 + 1, (uint32_t)(EMIT_CHUNK + 1));
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t off = offs[r0 + i], idx = sorted_idx[r0 + i];
+        float* R = rec + (size_t)idx * REC_F;
+        s_off[i] = off;
+        s_idx[i] = idx;
+        s_rmin[i] = __float_as_uint(R[10]);
+        s_rsz[i] = __float_as_uint(R[11]);
+        if (off >= o0) R[9] = __uint_as_float(off);  // the chunk in which the rank starts records its offset
     }
-    const uint32_t start = __shfl(off, 0, 64);  // ranks are in range for lane 0 of every launched wave
-    // one past the wave's last pair: offset + count of the last lane that has a rank
-    const int last = min(63, P - 1 - (r - lane));
-    const uint32_t end = __shfl(off, last, 64) + __shfl(tt, last, 64);
-    for (uint32_t o = start + (uint32_t)lane; o - (uint32_t)lane < end; o += 64) {
-        const bool act = o < end;
-        // owner: the largest lane j <= last with off_j <= o (offsets are non-decreasing; empty Gaussians
-        // share their successor's offset, so the largest such lane is the one that owns pair o)
-        int lo = 0, hi = last;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < EMIT_CHUNK / 256; k++) {
+        const uint32_t o = o0 + k * 256 + threadIdx.x;
+        if (o >= o1) break;
+        // owner: the largest i with s_off[i] <= o
+        int lo = 0, hi = cnt - 1;
+        while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            const uint32_t om = __shfl(off, mid, 64);
-            if (om <= o) lo = mid; else hi = mid - 1;
+            if (s_off[mid] <= o) lo = mid; else hi = mid - 1;
         }
-        const uint32_t o_off = __shfl(off, lo, 64);
-        const uint32_t o_idx = __shfl(idx, lo, 64);
-        const uint32_t o_rmin = __shfl(rmin, lo, 64);
-        const uint32_t o_rsz = __shfl(rsz, lo, 64);
-        if (act) {
-            const uint32_t w = o_rsz & 0xFFFFu;
-            const uint32_t li = o - o_off;
-            uint32_t y = (uint32_t)(((float)li + 0.5f) / (float)w);
-            if (y * w > li) y--;
-            if ((y + 1) * w <= li) y++;
-            const uint32_t x = li - y * w;
-            keys[o] = ((o_rmin >> 16) + y) * (uint32_t)gx + (o_rmin & 0xFFFFu) + x;
-            vals[o] = o_idx;
-        }
+        const uint32_t o_off = s_off[lo], o_rmin = s_rmin[lo], o_rsz = s_rsz[lo];
+        const uint32_t w = o_rsz & 0xFFFFu;
+        const uint32_t li = o - o_off;
+        uint32_t y = (uint32_t)(((float)li + 0.5f) / (float)w);
+        if (y * w > li) y--;
+        if ((y + 1) * w <= li) y++;
+        const uint32_t x = li - y * w;
+        keys[o] = ((o_rmin >> 16) + y) * (uint32_t)gx + (o_rmin & 0xFFFFu) + x;
+        vals[o] = s_idx[lo];
     }
 }
 
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, int P, int gx, int debug, hipStream_t s) {
-    hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, s, sorted_idx, tt_rank, offs, rec, keys, vals,
-                       P, gx);
+                uint32_t* vals, uint32_t* owner, int P, int64_t D, int gx, int debug, hipStream_t s) {
+    if (D <= 0) return GS_OK;
+    const uint32_t nchunks = (uint32_t)((D + EMIT_CHUNK - 1) / EMIT_CHUNK);
+    hipLaunchKernelGGL(emit_owner_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tt_rank, offs, P, (uint32_t)D, nchunks,
+                       owner);
+    GS_LAUNCH_CHECK("emit.owner", debug, s);
+    hipLaunchKernelGGL(emit_kernel, dim3(nchunks), dim3(256), 0, s, sorted_idx, offs, owner, rec, keys, vals, (uint32_t)D,
+                       nchunks, gx);
     GS_LAUNCH_CHECK("emit", debug, s);
     return GS_OK;
 }

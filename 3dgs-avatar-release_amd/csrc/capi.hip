@@ -153,7 +153,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
         uint32_t* v1 = (uint32_t*)(b + B.val1);
         { StageScope sc_("emit", s);
         rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
-                         (float*)(g + L.rec), k0, v0, a->P, I.gx, a->debug, s); }
+                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), a->P, D, I.gx, a->debug, s); }
         if (rc != GS_OK) return rc;
         const int bits = tile_bits(ntiles);
         { StageScope sc_("tile_sort", s);

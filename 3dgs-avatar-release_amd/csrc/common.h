@@ -55,9 +55,10 @@ static inline GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t key0, key1, val0, val1, hist, qlist, total;
+    size_t key0, key1, val0, val1, hist, qlist, owner, total;
     int nblk_sort;
 };
+#define EMIT_CHUNK 2048  // pairs emitted per workgroup
 static inline BinLayout bin_layout(int64_t D) {
     BinLayout L;
     size_t o = 0;
@@ -70,6 +71,7 @@ static inline BinLayout bin_layout(int64_t D) {
     L.val1 = take(n * 4);
     L.hist = take(sort_table_words(n) * 4);
     L.qlist = take(n * 16);  // per quadrant: compacted Gaussian indices the forward visited
+    L.owner = take((n / EMIT_CHUNK + 3) * 4);  // rank owning the first pair of every emission chunk (+ the last pair)
     L.total = o;
     return L;
 }
@@ -139,7 +141,7 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, ui
 int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
                       uint32_t* bsum, unsigned long long* count, int P, int debug, hipStream_t s);
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, int P, int gx, int debug, hipStream_t s);
+                uint32_t* vals, uint32_t* owner, int P, int64_t D, int gx, int debug, hipStream_t s);
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
 
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
