@@ -35,6 +35,29 @@ __device__ __forceinline__ float wave_ror1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
 
+// a[0..8] += (Gd dx, Gd dy, tdx dx, tdx dy, tdy dy, Gd, wgt gx, wgt gy, wgt gz) on the lanes of `mask` only
+__device__ __forceinline__ void masked_accumulate(float (&a)[9], unsigned long long mask, float Gd, float dx, float dy,
+                                                  float tdx, float tdy, float wgt, float gx, float gy, float gz) {
+    unsigned long long save;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"  // (the caller runs with all 64 lanes on; s_mov leaves SCC alone, s_and would not)
+        "v_fmac_f32 %[a0], %[Gd], %[dx]\n\t"
+        "v_fmac_f32 %[a1], %[Gd], %[dy]\n\t"
+        "v_fmac_f32 %[a2], %[tdx], %[dx]\n\t"
+        "v_fmac_f32 %[a3], %[tdx], %[dy]\n\t"
+        "v_fmac_f32 %[a4], %[tdy], %[dy]\n\t"
+        "v_add_f32 %[a5], %[a5], %[Gd]\n\t"
+        "v_fmac_f32 %[a6], %[w], %[gx]\n\t"
+        "v_fmac_f32 %[a7], %[w], %[gy]\n\t"
+        "v_fmac_f32 %[a8], %[w], %[gz]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]),
+          [a6] "+v"(a[6]), [a7] "+v"(a[7]), [a8] "+v"(a[8]), [sv] "=&s"(save)
+        : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt),
+          [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz));
+}
+
 // the nine per-entry values the inner loop reads
 struct Entry {
     float x, y, A2, B2, C2, o, r, g, b;
@@ -108,15 +131,22 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
     Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
-    uint32_t cur_row = 0, nxt_row = 0;  // gradient row (4 pair + quadrant) of the working entry / of `nxt`
+    uint32_t nxt_row = 0;  // gradient row (4 pair + quadrant) of the entry in `nxt`
     gather(lane, p0, p1, p2);
     convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by lane t at step t
     gather(64 + lane, p0, p1, p2);      // chunk 1 in flight during round 0
     __syncthreads();
 
-    float acc[9];
+    // Two accumulator sets, named by the PARITY of the chunk they belong to: during round R the lanes
+    // that have already taken their entry of chunk R (lane <= t) add into set R & 1, the others still
+    // add into the set of chunk R - 1.  A set is therefore complete for ALL lanes when round R + 1 ends
+    // ... i.e. it is stored (three full-wave stores) and cleared at the start of round R + 2, instead
+    // of every lane storing / clearing its own sums at its own switch step under a one-lane exec mask
+    // (where every instruction costs as much as a full-wave one).
+    float accA[9], accB[9];
 #pragma unroll
-    for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
+    for (int c9 = 0; c9 < 9; c9++) accA[c9] = accB[c9] = 0.f;
+    uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
     // index into pix[c][] of the pixel at this lane: (s - lane) mod 64, + 64 within a round
     uint32_t pidx = (uint32_t)((64 - lane) & 63);
     float pc[6];
@@ -126,81 +156,72 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // (pixel p starts at lane (64 - p) mod 64; fetch its Gtot from the lane that loaded it)
     float T = 1.0f, Rem = __shfl(gtot0, (int)pidx, 64);
 
-    // A finished entry's nine RAW sums go straight to its row in HBM, stored by the one lane that owns
-    // them (global stores count on vmcnt, so they never hold up the LDS waits of the step loop).  What
-    // is constant per Gaussian -- opacity, the conic combination of the two first moments, the -1/2 and
-    // 1/log2(e) factors -- is applied once per Gaussian by segment_reduce_kernel.
-    auto write_row = [&](size_t row) {
-        qrows[row * 2] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        qrows[row * 2 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        q8[row] = __float_as_uint(acc[8]);  // the ninth sum doubles as the "row written" mark
+    // A finished entry's nine RAW sums go to its row in HBM.  What is constant per Gaussian -- opacity,
+    // the conic combination of the two first moments, the -1/2 and 1/log2(e) factors -- is applied once
+    // per Gaussian by segment_reduce_kernel.
+    auto write_row = [&](size_t row, const float* a) {
+        qrows[row * 2] = make_float4(a[0], a[1], a[2], a[3]);
+        qrows[row * 2 + 1] = make_float4(a[4], a[5], a[6], a[7]);
+        q8[row] = __float_as_uint(a[8]);  // the ninth sum doubles as the "row written" mark
     };
 
-    // An entry k lives in its lane for the steps k .. k+63 and is stored at step k+64 when the lane
-    // takes entry k+64; the loop runs s = 0 .. m+62, so exactly the entries k <= m-2 get stored there and
-    // entry m-1 is still in its lane's registers at the end.
+    // An entry k lives in its lane for the steps k .. k+63; the loop runs s = 0 .. m+62, so every entry
+    // k <= m-2 has seen all its pixels when the loop ends and entry m-1 has seen all pixels that reach it.
     const int total = m + 63;
-    for (int s0 = 0; s0 < total; s0 += 64) {
+    auto run_round = [&](const int s0, float (&X)[9], uint32_t& rowX, float (&Y)[9]) {
         if (s0 > 0) {
             // round start: every lane took its entry of the previous chunk out of `nxt` during the
-            // previous round.  The chunk that was in flight -> `nxt`; the chunk after it -> in flight.
+            // previous round.  X holds the finished sums of the chunk before that one: store them.  The
+            // chunk that was in flight -> `nxt`; the chunk after it -> in flight.
+            if (s0 >= 128) write_row(rowX, X);
             convert(p0, p1, p2, nxt, nxt_row);
             gather(s0 + 64 + lane, p0, p1, p2);
             pidx -= 64u;
         }
+        rowX = nxt_row;
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) X[c9] = 0.f;
         const int tend = min(64, total - s0);
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
-            if (lane == t) {
-                if (s0 > 0) write_row(cur_row);  // this lane has seen all 64 pixels with its entry
-                // ... and take the next entry
-                cur = nxt;
-                cur_row = nxt_row;
+            if (lane == t) cur = nxt;  // this lane takes its entry of the new chunk
+            const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
+            const float pxf = pc[3], pyf = pc[4];
+            const uint32_t lim = __float_as_uint(pc[5]);
+            // next step's pixel constants, fetched now
+            pidx += 1u;
 #pragma unroll
-                for (int c9 = 0; c9 < 9; c9++) acc[c9] = 0.f;
-            }
-            {
-                const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
-                const float pxf = pc[3], pyf = pc[4];
-                const uint32_t lim = __float_as_uint(pc[5]);
-                // next step's pixel constants, fetched now
-                pidx += 1u;
-#pragma unroll
-                for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
-                const float dx = cur.x - pxf, dy = cur.y - pyf;
-                // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
-                const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);
-                const float G = __builtin_amdgcn_exp2f(power2);
-                const float al = fminf(0.99f, cur.o * G);
-                // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
-                // power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that has no
-                // entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's
-                // relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
-                const float a1 = (power2 <= 0.0f) ? al : 0.f;
-                const float a2 = (s < lim) ? a1 : 0.f;
-                const bool valid = a2 >= (1.0f / 255.0f);
-                const float alpha = valid ? a2 : 0.f;
-                const float Gv = valid ? G : 0.f;
-                const float wgt = alpha * T;
-                const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
-                Rem = __builtin_fmaf(-cg, wgt, Rem);
-                const float one_m = 1.f - alpha;
-                const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
-                T *= one_m;
-                const float Gd = Gv * dL_dalpha;  // G dL/dalpha; times opacity it is G dL/dG (applied when parked)
-                const float tdx = Gd * dx, tdy = Gd * dy;
-                // sums:  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
-                //        6..8: w g_c = dL/dcolor
-                acc[0] += tdx;
-                acc[1] += tdy;
-                acc[2] += tdx * dx;
-                acc[3] += tdx * dy;
-                acc[4] += tdy * dy;
-                acc[5] += Gd;
-                acc[6] += wgt * g.x;
-                acc[7] += wgt * g.y;
-                acc[8] += wgt * g.z;
-            }
+            for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
+            const float dx = cur.x - pxf, dy = cur.y - pyf;
+            // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
+            const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);
+            const float G = __builtin_amdgcn_exp2f(power2);
+            const float al = fminf(0.99f, cur.o * G);
+            // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
+            // power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that has no
+            // entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's
+            // relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
+            const float a1 = (power2 <= 0.0f) ? al : 0.f;
+            const float a2 = (s < lim) ? a1 : 0.f;
+            const bool valid = a2 >= (1.0f / 255.0f);
+            const float alpha = valid ? a2 : 0.f;
+            const float Gv = valid ? G : 0.f;
+            const float wgt = alpha * T;
+            const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
+            Rem = __builtin_fmaf(-cg, wgt, Rem);
+            const float one_m = 1.f - alpha;
+            const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
+            T *= one_m;
+            const float Gd = Gv * dL_dalpha;  // G dL/dalpha; times opacity it is G dL/dG (applied per Gaussian later)
+            const float tdx = Gd * dx, tdy = Gd * dy;
+            // sums:  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
+            //        6..8: w g_c = dL/dcolor     (t = Gd)
+            // X += ... on the lanes <= t, Y += ... on the others: the same nine instructions issued twice
+            // under complementary exec masks.  (Written as if / else the compiler either flattens the two
+            // blocks into three selects per sum or indexes the sets through scratch memory.)
+            const unsigned long long mx = (t >= 63) ? ~0ull : ((2ull << t) - 1ull);
+            masked_accumulate(X, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
+            masked_accumulate(Y, ~mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
             // the pixel moves on to the next entry = the next lane
             T = wave_ror1(T);
             Rem = wave_ror1(Rem);
@@ -212,9 +233,20 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             step(t + 1);
         }
         if (t < tend) step(t);
+    };
+    for (int s0 = 0; s0 < total; s0 += 128) {
+        run_round(s0, accA, rowA, accB);
+        if (s0 + 64 < total) run_round(s0 + 64, accB, rowB, accA);
     }
-    // entry m-1 was never stored
-    if (lane == ((m - 1) & 63)) write_row(cur_row);
+    {
+        // the two chunks still in the sets: the one taken during the last round (only entry m-1 can be in
+        // it) and the one before it (complete for the lanes that switched, and holding entry m-1 otherwise)
+        const int last_round = (total - 1) >> 6;
+        const bool odd = last_round & 1;
+        const int k_new = 64 * last_round + lane, k_old = k_new - 64;
+        if (k_new <= m - 1) write_row(odd ? rowB : rowA, odd ? accB : accA);
+        if (last_round >= 1 && k_old <= m - 1) write_row(odd ? rowA : rowB, odd ? accA : accB);
+    }
 }
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
