@@ -35,27 +35,44 @@ __device__ __forceinline__ float wave_ror1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
 }
 
-// a[0..8] += (Gd dx, Gd dy, tdx dx, tdx dy, tdy dy, Gd, wgt gx, wgt gy, wgt gz) on the lanes of `mask` only
-__device__ __forceinline__ void masked_accumulate(float (&a)[9], unsigned long long mask, float Gd, float dx, float dy,
-                                                  float tdx, float tdy, float wgt, float gx, float gy, float gz) {
+// x[0..8] += (Gd dx, Gd dy, tdx dx, tdx dy, tdy dy, Gd, wgt gx, wgt gy, wgt gz) on the lanes of `mask`,
+// y[0..8] += the same on all other lanes: the nine instructions issued twice under complementary exec
+// masks.  (Written as if / else the compiler either flattens the two blocks into three selects per sum
+// or indexes the sets through scratch memory.)  The caller runs with all 64 lanes on.
+__device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], unsigned long long mask, float Gd, float dx,
+                                                 float dy, float tdx, float tdy, float wgt, float gx, float gy,
+                                                 float gz) {
     unsigned long long save;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[m]\n\t"  // (the caller runs with all 64 lanes on; s_mov leaves SCC alone, s_and would not)
-        "v_fmac_f32 %[a0], %[Gd], %[dx]\n\t"
-        "v_fmac_f32 %[a1], %[Gd], %[dy]\n\t"
-        "v_fmac_f32 %[a2], %[tdx], %[dx]\n\t"
-        "v_fmac_f32 %[a3], %[tdx], %[dy]\n\t"
-        "v_fmac_f32 %[a4], %[tdy], %[dy]\n\t"
-        "v_add_f32 %[a5], %[a5], %[Gd]\n\t"
-        "v_fmac_f32 %[a6], %[w], %[gx]\n\t"
-        "v_fmac_f32 %[a7], %[w], %[gy]\n\t"
-        "v_fmac_f32 %[a8], %[w], %[gz]\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"
+        "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"
+        "v_fmac_f32 %[x2], %[tdx], %[dx]\n\t"
+        "v_fmac_f32 %[x3], %[tdx], %[dy]\n\t"
+        "v_fmac_f32 %[x4], %[tdy], %[dy]\n\t"
+        "v_add_f32 %[x5], %[x5], %[Gd]\n\t"
+        "v_fmac_f32 %[x6], %[w], %[gx]\n\t"
+        "v_fmac_f32 %[x7], %[w], %[gy]\n\t"
+        "v_fmac_f32 %[x8], %[w], %[gz]\n\t"
+        "s_andn2_b64 exec, %[sv], %[m]\n\t"
+        "v_fmac_f32 %[y0], %[Gd], %[dx]\n\t"
+        "v_fmac_f32 %[y1], %[Gd], %[dy]\n\t"
+        "v_fmac_f32 %[y2], %[tdx], %[dx]\n\t"
+        "v_fmac_f32 %[y3], %[tdx], %[dy]\n\t"
+        "v_fmac_f32 %[y4], %[tdy], %[dy]\n\t"
+        "v_add_f32 %[y5], %[y5], %[Gd]\n\t"
+        "v_fmac_f32 %[y6], %[w], %[gx]\n\t"
+        "v_fmac_f32 %[y7], %[w], %[gy]\n\t"
+        "v_fmac_f32 %[y8], %[w], %[gz]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]),
-          [a6] "+v"(a[6]), [a7] "+v"(a[7]), [a8] "+v"(a[8]), [sv] "=&s"(save)
+        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
+          [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]),
+          [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]), [y7] "+v"(y[7]), [y8] "+v"(y[8]),
+          [sv] "=&s"(save)
         : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt),
-          [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz));
+          [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
+        : "scc");
 }
 
 // the nine per-entry values the inner loop reads
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 #pragma unroll
         for (int c9 = 0; c9 < 9; c9++) X[c9] = 0.f;
         const int tend = min(64, total - s0);
+        unsigned long long mx = 1ull;  // lanes <= t, kept up to date step by step
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
             if (lane == t) cur = nxt;  // this lane takes its entry of the new chunk
@@ -216,12 +234,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float tdx = Gd * dx, tdy = Gd * dy;
             // sums:  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
             //        6..8: w g_c = dL/dcolor     (t = Gd)
-            // X += ... on the lanes <= t, Y += ... on the others: the same nine instructions issued twice
-            // under complementary exec masks.  (Written as if / else the compiler either flattens the two
-            // blocks into three selects per sum or indexes the sets through scratch memory.)
-            const unsigned long long mx = (t >= 63) ? ~0ull : ((2ull << t) - 1ull);
-            masked_accumulate(X, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
-            masked_accumulate(Y, ~mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
+            // X += ... on the lanes <= t (they have taken their entry of this round's chunk), Y += ... on the others
+            split_accumulate(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
+            mx = (mx << 1) | 1ull;
             // the pixel moves on to the next entry = the next lane
             T = wave_ror1(T);
             Rem = wave_ror1(Rem);
