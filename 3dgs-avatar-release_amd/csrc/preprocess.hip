@@ -6,6 +6,26 @@
 #include "common.h"
 #include "gs_math.h"
 
+// SH -> RGB of Gaussian i.  The (M,3) block of a Gaussian is 3M contiguous floats read by ONE lane; for
+// the full 16-coefficient layout it is 192 bytes at a 16-byte aligned offset, fetched as twelve dwordx4
+// loads instead of 48 dword loads (a quarter of the load instructions, each lane touching whole 16-byte
+// pieces of its sectors).  Same arithmetic either way.
+__device__ __forceinline__ float3 load_and_eval_sh(int deg, int M, const float3 p, const float3 campos,
+                                                   const float* __restrict__ shs, int i, uint32_t* clamped) {
+    const float* g = shs + (size_t)i * M * 3;
+    if (M == 16 && ((uintptr_t)shs & 15u) == 0) {  // wave-uniform
+        float l[48];
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float4 v = g4[k];
+            l[4 * k] = v.x; l[4 * k + 1] = v.y; l[4 * k + 2] = v.z; l[4 * k + 3] = v.w;
+        }
+        return sh_to_rgb(deg, p, campos, l, clamped);
+    }
+    return sh_to_rgb(deg, p, campos, g, clamped);
+}
+
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int deg, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
     float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 if (colors_precomp) {
                     col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
                 } else {
-                    col = sh_to_rgb(deg, p, make_float3(campos[0], campos[1], campos[2]), shs + (size_t)i * M * 3, &cl);
+                    col = load_and_eval_sh(deg, M, p, make_float3(campos[0], campos[1], campos[2]), shs, i, &cl);
                 }
                 depth = pv.z;
                 radius = r;
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
             col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
         } else {
             const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
-            col = sh_to_rgb(deg, p, make_float3(campos[0], campos[1], campos[2]), shs + (size_t)i * M * 3, &cl);
+            col = load_and_eval_sh(deg, M, p, make_float3(campos[0], campos[1], campos[2]), shs, i, &cl);
         }
         r1.z = col.x;
         r1.w = col.y;
