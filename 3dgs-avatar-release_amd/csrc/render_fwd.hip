@@ -70,7 +70,6 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             const int slot = __popcll(bal & lt_mask);
             const uint32_t k = kcount + (uint32_t)slot;  // compacted index of this entry
             s.c.w = __uint_as_float((uint32_t)(base + lane + 1));  // position in the tile's list (1-based)
-            s.b.w = __uint_as_float(k + 1u);
             srec[slot * 3] = s.a;
             srec[slot * 3 + 1] = s.b;
             srec[slot * 3 + 2] = s.c;
@@ -89,6 +88,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         // uniform, it is rebuilt from SGPRs with a v_mov per dword and a dozen scalar adds per entry, and
         // the CU's single scalar unit becomes the bottleneck.
         const char* sp = reinterpret_cast<const char*>(srec) + vzero;
+        const uint32_t kbase = kcount - (uint32_t)cnt;  // compacted index of this batch's first entry
         for (int j = 0; j < cnt; j++) {
             const float4 a = *reinterpret_cast<const float4*>(sp);
             const float4 b = *reinterpret_cast<const float4*>(sp + 16);
@@ -99,8 +99,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
             const float al = fminf(0.99f, b.y * G);
-            const float a1 = (power2 <= 0.0f) ? al : 0.f;
-            const float a2 = (a1 >= (1.0f / 255.0f)) ? a1 : 0.f;  // alpha, or 0 if this pair is rejected
+            const float a2 = (power2 <= 0.0f && al >= (1.0f / 255.0f)) ? al : 0.f;  // alpha, or 0 if the pair is rejected
             const float test_T = T * (1.f - a2);                  // == T for a rejected pair, < 0 for a frozen pixel
             const bool pass = test_T >= 0.0001f;
             const float wT = a2 * T;
@@ -109,10 +108,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
-            const bool blended = w > 0.f;
-            last = blended ? __float_as_uint(c.w) : last;
-            last_k = blended ? __float_as_uint(b.w) : last_k;
+            last_k = (w > 0.f) ? (kbase + (uint32_t)j + 1u) : last_k;  // (a wave-uniform value: no LDS operand)
         }
+        // the last contributor's position in the TILE's list (n_contrib), looked up once per batch
+        if (last_k > kbase) last = __float_as_uint(srec[(last_k - 1u - kbase) * 3 + 2].w);
         live = __ballot(T > 0.f) != 0ull;  // every pixel of the quadrant frozen: stop
     }
     {
