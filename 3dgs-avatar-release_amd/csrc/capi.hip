@@ -315,6 +315,28 @@ int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL
     return launch_l1_loss(x, y, n, loss, dL_dx, (float*)workspace, (hipStream_t)stream);
 }
 
+int gs_ssim_workspace_bytes(int32_t C, int32_t H, int32_t W, size_t* out) {
+    if (!out || C <= 0 || H <= 0 || W <= 0) return GS_E_BAD_ARG;
+    *out = ssim_ws_bytes(C, H, W);
+    return GS_OK;
+}
+int gs_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, float* ssim_out, float* dm_dmu1,
+                    float* dm_dsigma1_sq, float* dm_dsigma12, void* workspace, size_t workspace_bytes, void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_out || !workspace) return GS_E_BAD_ARG;
+    if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr)) return GS_E_BAD_ARG;
+    if (workspace_bytes < ssim_ws_bytes(C, H, W)) return GS_E_WORKSPACE;
+    return launch_ssim_forward(C, H, W, img1, img2, ssim_out, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)workspace,
+                               (hipStream_t)stream);
+}
+int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* dm_dmu1,
+                     const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dssim, float* dL_dimg1,
+                     void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dssim || !dL_dimg1)
+        return GS_E_BAD_ARG;
+    return launch_ssim_backward(C, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dssim, dL_dimg1,
+                                (hipStream_t)stream);
+}
+
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {
     if (!geom || !out || P < 0) return GS_E_BAD_ARG;
     const GeomLayout L = geom_layout(P);

@@ -147,6 +147,13 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int 
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
 size_t l1_ws_bytes(int64_t n);
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
+// SSIM of two (C,H,W) images + the three partial-derivative maps its backward filters (loss.hip)
+size_t ssim_ws_bytes(int C, int H, int W);
+int launch_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_out, float* dm_dmu1,
+                        float* dm_ds1, float* dm_ds12, float* partial, hipStream_t s);
+int launch_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
+                         const float* dm_ds1, const float* dm_ds12, const float* dL_dssim, float* dL_dimg1,
+                         hipStream_t s);
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
                       hipStream_t s);

@@ -4,6 +4,7 @@
 // |x - y| per block; a second, single-block pass adds the partials in index order.  No atomics: the
 // result is bitwise reproducible.
 #include "common.h"
+#include <math.h>
 
 #define L1_THREADS 256
 #define L1_MAX_BLOCKS 1024
@@ -68,5 +69,198 @@ int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float
     GS_LAUNCH_CHECK("l1_loss.partial", 0, s);
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, partial, blocks, inv_n, loss);
     GS_LAUNCH_CHECK("l1_loss.final", 0, s);
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SSIM (utils/loss_utils.py:27-67: 11x11 Gaussian window, sigma 1.5, zero
+// padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements) with its gradient w.r.t. the first image.
+// The reference runs five depthwise conv2d launches plus ~15 elementwise ones and lets autograd replay
+// them backwards.  Here: one forward kernel (16x16 output tile per workgroup, 26x26 halo tiles of both
+// images in LDS, the 121-tap window applied as two 11-tap passes, five moments at once) that also
+// emits the three partial-derivative maps the backward needs, and one backward kernel that filters
+// those three maps with the same window and combines them with the images.  Reductions are two-stage
+// and ordered: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+#define SS_T 16            // output tile edge
+#define SS_R 5             // window radius
+#define SS_H (SS_T + 2 * SS_R)  // halo tile edge (26)
+#define SS_C1 0.0001f
+#define SS_C2 0.0009f
+
+struct SsimWindow { float w[11]; };
+
+__global__ __launch_bounds__(SS_T* SS_T) void ssim_fwd_kernel(int H, int W, const float* __restrict__ img1,
+                                                              const float* __restrict__ img2, SsimWindow win,
+                                                              float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1,
+                                                              float* __restrict__ dm_ds12, float* __restrict__ partial) {
+    __shared__ float t1[SS_H][SS_H + 1], t2[SS_H][SS_H + 1];
+    __shared__ float hx[5][SS_H][SS_T + 1];
+    __shared__ float ws[SS_T * SS_T / 64];
+    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int e = tid; e < SS_H * SS_H; e += SS_T * SS_T) {
+        const int r = e / SS_H, c = e - r * SS_H;
+        const int y = y0 + r - SS_R, x = x0 + c - SS_R;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
+        t1[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
+        t2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    // horizontal pass: 26 rows x 16 columns, five moments
+    for (int e = tid; e < SS_H * SS_T; e += SS_T * SS_T) {
+        const int r = e / SS_T, c = e - r * SS_T;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float a = t1[r][c + k], b = t2[r][c + k], w = win.w[k];
+            m1 += w * a;
+            m2 += w * b;
+            e11 += w * (a * a);
+            e22 += w * (b * b);
+            e12 += w * (a * b);
+        }
+        hx[0][r][c] = m1; hx[1][r][c] = m2; hx[2][r][c] = e11; hx[3][r][c] = e22; hx[4][r][c] = e12;
+    }
+    __syncthreads();
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        mu1 += w * hx[0][ty + k][tx];
+        mu2 += w * hx[1][ty + k][tx];
+        e11 += w * hx[2][ty + k][tx];
+        e22 += w * hx[3][ty + k][tx];
+        e12 += w * hx[4][ty + k][tx];
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    float val = 0.f;
+    if (x < W && y < H) {
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float A = 2.f * mu12 + SS_C1, B = 2.f * s12 + SS_C2;
+        const float C = mu1_sq + mu2_sq + SS_C1, D = s1 + s2 + SS_C2;
+        const float inv_cd = 1.0f / (C * D);
+        val = A * B * inv_cd;
+        if (dm_dmu1) {
+            // ssim as a function of (mu1, E[x^2], E[xy]) of this window; s1 and s12 depend on mu1 too
+            const float d_s1 = -val / D;              // d ssim / d s1   = -A B / (C D^2)
+            const float d_s12 = 2.f * A * inv_cd;     // d ssim / d s12  =  2 A / (C D)
+            const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * val / C - 2.f * mu1 * d_s1 - mu2 * d_s12;
+            const size_t o = plane + (size_t)y * W + x;
+            dm_dmu1[o] = d_mu1;
+            dm_ds1[o] = d_s1;
+            dm_ds12[o] = d_s12;
+        }
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) val += __shfl_xor(val, k, 64);
+    if ((tid & 63) == 0) ws[tid >> 6] = val;
+    __syncthreads();
+    if (tid == 0) partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void ssim_final_kernel(const float* __restrict__ partial, int nparts, float inv_n,
+                                                         float* __restrict__ out) {
+    __shared__ float ws[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float acc = 0.f;
+    for (int i = tid; i < nparts; i += 256) acc += partial[i];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    if (lane == 0) ws[wid] = acc;
+    __syncthreads();
+    if (tid == 0) out[0] = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_n;
+}
+
+// dL/dimg1(p) = g/n * sum_q w(q - p) [ dm_dmu1(q) + 2 img1(p) dm_ds1(q) + img2(p) dm_ds12(q) ]
+__global__ __launch_bounds__(SS_T* SS_T) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
+                                                              const float* __restrict__ img2, SsimWindow win,
+                                                              const float* __restrict__ dm_dmu1,
+                                                              const float* __restrict__ dm_ds1,
+                                                              const float* __restrict__ dm_ds12,
+                                                              const float* __restrict__ dL_dssim, float inv_n,
+                                                              float* __restrict__ dL_dimg1) {
+    __shared__ float t[3][SS_H][SS_H + 1];
+    __shared__ float hx[3][SS_H][SS_T + 1];
+    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int e = tid; e < SS_H * SS_H; e += SS_T * SS_T) {
+        const int r = e / SS_H, c = e - r * SS_H;
+        const int y = y0 + r - SS_R, x = x0 + c - SS_R;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
+        const size_t o = plane + (size_t)y * W + x;
+        t[0][r][c] = in ? dm_dmu1[o] : 0.f;
+        t[1][r][c] = in ? dm_ds1[o] : 0.f;
+        t[2][r][c] = in ? dm_ds12[o] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < SS_H * SS_T; e += SS_T * SS_T) {
+        const int r = e / SS_T, c = e - r * SS_T;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            a0 += w * t[0][r][c + k];
+            a1 += w * t[1][r][c + k];
+            a2 += w * t[2][r][c + k];
+        }
+        hx[0][r][c] = a0; hx[1][r][c] = a1; hx[2][r][c] = a2;
+    }
+    __syncthreads();
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        f0 += w * hx[0][ty + k][tx];
+        f1 += w * hx[1][ty + k][tx];
+        f2 += w * hx[2][ty + k][tx];
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x < W && y < H) {
+        const size_t o = plane + (size_t)y * W + x;
+        const float g = dL_dssim[0] * inv_n;
+        dL_dimg1[o] = g * (f0 + 2.f * img1[o] * f1 + img2[o] * f2);
+    }
+}
+
+static SsimWindow ssim_window() {
+    // utils/loss_utils.py:27-29: exp(-(x - 5)^2 / (2 * 1.5^2)) evaluated in double, stored as fp32, normalised in fp32
+    SsimWindow w;
+    float s = 0.f;
+    for (int k = 0; k < 11; k++) {
+        w.w[k] = (float)exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5));
+        s += w.w[k];
+    }
+    for (int k = 0; k < 11; k++) w.w[k] /= s;
+    return w;
+}
+
+static inline int ssim_tiles(int v) { return (v + SS_T - 1) / SS_T; }
+size_t ssim_ws_bytes(int C, int H, int W) { return (size_t)C * ssim_tiles(H) * ssim_tiles(W) * sizeof(float); }
+
+int launch_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_out, float* dm_dmu1,
+                        float* dm_ds1, float* dm_ds12, float* partial, hipStream_t s) {
+    const dim3 grid(ssim_tiles(W), ssim_tiles(H), C);
+    StageScope st("ssim_fwd", s);
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
+                       dm_ds12, partial);
+    GS_LAUNCH_CHECK("ssim.forward", 0, s);
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)(grid.x * grid.y * grid.z),
+                       1.0f / ((float)C * (float)H * (float)W), ssim_out);
+    GS_LAUNCH_CHECK("ssim.final", 0, s);
+    return GS_OK;
+}
+
+int launch_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
+                         const float* dm_ds1, const float* dm_ds12, const float* dL_dssim, float* dL_dimg1,
+                         hipStream_t s) {
+    const dim3 grid(ssim_tiles(W), ssim_tiles(H), C);
+    StageScope st("ssim_bwd", s);
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SS_T * SS_T), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
+                       dm_ds12, dL_dssim, 1.0f / ((float)C * (float)H * (float)W), dL_dimg1);
+    GS_LAUNCH_CHECK("ssim.backward", 0, s);
     return GS_OK;
 }

@@ -119,6 +119,62 @@ def l1_loss(network_output, gt):
     return _L1Loss.apply(network_output.contiguous(), gt.contiguous())
 
 
+class _Ssim(torch.autograd.Function):
+    """Mean SSIM of two (C,H,W) images; gradient w.r.t. the first (gs_ssim_forward / gs_ssim_backward)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        L = _lib.load()
+        C, H, W = (int(v) for v in img1.shape)
+        out = torch.empty((), dtype=torch.float32, device=img1.device)
+        need = img1.requires_grad
+        maps = torch.empty((3, C, H, W), dtype=torch.float32, device=img1.device) if need else None
+        ws = torch.empty(_lib.nbytes(L.gs_ssim_workspace_bytes, C, H, W), dtype=torch.uint8, device=img1.device)
+        with torch.cuda.device(img1.device):
+            sptr = ctypes.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)
+            _lib.check(L.gs_ssim_forward(C, H, W, img1.data_ptr(), img2.data_ptr(), out.data_ptr(),
+                                         _lib.ptr(maps[0]) if need else None, _lib.ptr(maps[1]) if need else None,
+                                         _lib.ptr(maps[2]) if need else None, ws.data_ptr(), ws.numel(), sptr))
+        if need:
+            ctx.save_for_backward(img1, img2, maps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, maps = ctx.saved_tensors
+        L = _lib.load()
+        C, H, W = (int(v) for v in img1.shape)
+        grad = torch.empty_like(img1)
+        g = g.to(torch.float32).contiguous()
+        with torch.cuda.device(img1.device):
+            sptr = ctypes.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)
+            _lib.check(L.gs_ssim_backward(C, H, W, img1.data_ptr(), img2.data_ptr(), maps[0].data_ptr(),
+                                          maps[1].data_ptr(), maps[2].data_ptr(), g.data_ptr(), grad.data_ptr(), sptr))
+        return grad, None
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """utils/loss_utils.py:37-67 `ssim` (11x11 Gaussian window, sigma 1.5, zero padding) as two fused HIP kernels
+    with the gradient w.r.t. `img1` (train.py:123 uses `1.0 - ssim(image, gt_image)`).
+    (C,H,W) or (1,C,H,W) fp32 device tensors; the target image gets no gradient (it never needs one in the
+    reference).  Only the reference's defaults (window 11, mean over everything) are implemented."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("ssim: only window_size=11, size_average=True (the reference's call sites) are implemented")
+    if not (img1.is_cuda and img2.is_cuda):
+        raise RuntimeError("ssim: both tensors must live on the GPU (the fused HIP kernels have no CPU fallback)")
+    if img1.dtype != torch.float32 or img2.dtype != torch.float32:
+        raise TypeError("ssim: fp32 tensors expected")
+    if img1.shape != img2.shape:
+        raise ValueError("ssim: shapes differ")
+    if img1.dim() == 4 and img1.shape[0] == 1:
+        img1, img2 = img1[0], img2[0]
+    if img1.dim() != 3 or img1.numel() == 0:
+        raise ValueError("ssim: (C,H,W) images expected")
+    if img2.requires_grad:
+        raise NotImplementedError("ssim: gradient w.r.t. the second image is not implemented")
+    return _Ssim.apply(img1.contiguous(), img2.contiguous())
+
+
 class DensifyStats(object):
     """max_radii2D / xyz_gradient_accum / denom bookkeeping of train.py:217-220 and
     scene/gaussian_model.py:464-466."""

@@ -136,6 +136,19 @@ int gs_l1_loss_workspace_bytes(int64_t n, size_t* out);
 int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* SSIM half of row N2: utils/loss_utils.py:27-67 `ssim(img1, img2)` (window 11, sigma 1.5, zero padding,
+ * C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W elements; train.py:123 uses 1 - ssim as the D-SSIM loss).
+ * gs_ssim_forward writes ssim_out[0] and, when the three map pointers are non-NULL (all or none), the
+ * per-element partial derivatives of the SSIM map w.r.t. the window mean, variance and covariance, each
+ * C*H*W floats.  gs_ssim_backward turns them into dL/dimg1 given the device scalar dL/dssim. ---- */
+int gs_ssim_workspace_bytes(int32_t C, int32_t H, int32_t W, size_t* out);
+int gs_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, float* ssim_out,
+                    float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* dm_dmu1,
+                     const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dssim, float* dL_dimg1,
+                     void* stream);
+
 /* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
  *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
  *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))

@@ -630,6 +630,80 @@ double or_l1_loss(long long n, const float* x, const float* y, float* grad) {
     return acc / (double)n;
 }
 
+/* N2: SSIM of utils/loss_utils.py:27-67 -- 11x11 window = outer product of the normalised 1-D Gaussian
+ * (sigma 1.5; 1-D weights and their products held in fp32 as the reference's tensors are), conv2d with zero
+ * padding 5 per channel, C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W elements -- and the gradient of that
+ * mean w.r.t. img1 (what autograd derives).  Accumulation in double: direct 121-tap sums. */
+double or_ssim(int C, int H, int W, const float* img1, const float* img2, float* grad1) {
+    float g1[11], s = 0.f;
+    for (int k = 0; k < 11; k++) { g1[k] = (float)exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); s += g1[k]; }
+    for (int k = 0; k < 11; k++) g1[k] /= s;
+    float w2[11][11];
+    for (int i = 0; i < 11; i++)
+        for (int j = 0; j < 11; j++) w2[i][j] = g1[i] * g1[j];
+    const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+    const size_t n = (size_t)C * H * W;
+    double* dmu = (double*)malloc(n * sizeof(double));
+    double* ds1 = (double*)malloc(n * sizeof(double));
+    double* ds12 = (double*)malloc(n * sizeof(double));
+    double total = 0.0;
+    for (int c = 0; c < C; c++) {
+        const float* a = img1 + (size_t)c * H * W;
+        const float* b = img2 + (size_t)c * H * W;
+        double chan = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : chan)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                double mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+                for (int i = 0; i < 11; i++) {
+                    const int yy = y + i - 5;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int j = 0; j < 11; j++) {
+                        const int xx = x + j - 5;
+                        if (xx < 0 || xx >= W) continue;
+                        const double w = w2[i][j], p = a[(size_t)yy * W + xx], q = b[(size_t)yy * W + xx];
+                        mu1 += w * p; mu2 += w * q; e11 += w * p * p; e22 += w * q * q; e12 += w * p * q;
+                    }
+                }
+                const double s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+                const double A = 2 * mu1 * mu2 + C1, B = 2 * s12 + C2, Cc = mu1 * mu1 + mu2 * mu2 + C1, D = s1 + s2 + C2;
+                const double v = A * B / (Cc * D);
+                chan += v;
+                const size_t o = (size_t)c * H * W + (size_t)y * W + x;
+                ds1[o] = -v / D;
+                ds12[o] = 2 * A / (Cc * D);
+                dmu[o] = 2 * mu2 * B / (Cc * D) - 2 * mu1 * v / Cc - 2 * mu1 * ds1[o] - mu2 * ds12[o];
+            }
+        total += chan;
+    }
+    if (grad1) {
+        for (int c = 0; c < C; c++) {
+            const float* a = img1 + (size_t)c * H * W;
+            const float* b = img2 + (size_t)c * H * W;
+#pragma omp parallel for schedule(static)
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    double f0 = 0, f1 = 0, f2 = 0;
+                    for (int i = 0; i < 11; i++) {
+                        const int yy = y + i - 5;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int j = 0; j < 11; j++) {
+                            const int xx = x + j - 5;
+                            if (xx < 0 || xx >= W) continue;
+                            const size_t o = (size_t)c * H * W + (size_t)yy * W + xx;
+                            const double w = w2[i][j];
+                            f0 += w * dmu[o]; f1 += w * ds1[o]; f2 += w * ds12[o];
+                        }
+                    }
+                    const size_t o = (size_t)y * W + x;
+                    grad1[(size_t)c * H * W + o] = (float)((f0 + 2.0 * a[o] * f1 + b[o] * f2) / (double)n);
+                }
+        }
+    }
+    free(dmu); free(ds1); free(ds12);
+    return total / (double)n;
+}
+
 void or_set_num_threads(int n) {
 #ifdef _OPENMP
     extern void omp_set_num_threads(int);

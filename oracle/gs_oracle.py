@@ -221,6 +221,17 @@ def l1_loss(x, y):
     return float(v), g.reshape(np.shape(x))
 
 
+def ssim(img1, img2):
+    """N2 restatement: (mean SSIM of two (C,H,W) images as float64, its gradient w.r.t. img1 as fp32)."""
+    a, b = _f32(img1), _f32(img2)
+    assert a.shape == b.shape and a.ndim == 3
+    g = np.zeros(a.shape, np.float32)
+    fn = lib().or_ssim
+    fn.restype = ctypes.c_double
+    v = fn(c_int(a.shape[0]), c_int(a.shape[1]), c_int(a.shape[2]), _ptr(a), _ptr(b), _ptr(g))
+    return float(v), g
+
+
 def set_num_threads(n):
     lib().or_set_num_threads(c_int(int(n)))
 

@@ -55,3 +55,23 @@ def rel_to_max(a, b):
     b = np.asarray(b, np.float64)
     m = max(np.abs(b).max(), 1e-30)
     return np.abs(a - b).max() / m
+
+
+def ssim_float64(img1, img2):
+    """Independent float64 restatement of the SSIM the oracle implements (window 11, sigma 1.5 with fp32 window
+    entries, zero padding, C1 = 1e-4, C2 = 9e-4, mean): returns (value, d value / d img1) via torch autograd."""
+    import torch
+    import torch.nn.functional as F
+    g1 = torch.tensor([np.float32(np.exp(-(k - 5) ** 2 / (2 * 1.5 ** 2))) for k in range(11)], dtype=torch.float32)
+    g1 = g1 / g1.sum()
+    c = img1.shape[0]
+    w = (g1[:, None] @ g1[None, :]).double()[None, None].repeat(c, 1, 1, 1)
+    a = torch.from_numpy(np.asarray(img1, np.float32)).double()[None].requires_grad_(True)
+    b = torch.from_numpy(np.asarray(img2, np.float32)).double()[None]
+    conv = lambda t: F.conv2d(t, w, padding=5, groups=c)
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 ** 2, conv(b * b) - mu2 ** 2, conv(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))
+    v = m.mean()
+    v.backward()
+    return float(v.detach()), a.grad[0].numpy()

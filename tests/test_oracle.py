@@ -277,3 +277,23 @@ def test_l1_loss_closed_forms(oracle):
     v, g = oracle.l1_loss(a, b)
     assert v == pytest.approx(float(loss), rel=1e-6)
     assert np.array_equal(g, ta.grad.numpy())
+
+
+def test_ssim_oracle_vs_float64_autograd_and_closed_forms(oracle):
+    """N2 oracle (utils/loss_utils.py:27-67): identical images give exactly 1 with zero gradient; value and
+    gradient agree with an independent float64 conv2d + autograd restatement; ragged sizes (zero padding)."""
+    rng = np.random.default_rng(11)
+    a = rng.random((3, 23, 31), dtype=np.float32)
+    v, g = oracle.ssim(a, a)
+    assert v == pytest.approx(1.0, abs=1e-12)
+    assert np.abs(g).max() < 1e-9
+    for shape in [(3, 40, 37), (1, 11, 64), (3, 5, 7)]:
+        a = rng.random(shape, dtype=np.float32)
+        b = np.clip(a + 0.15 * rng.standard_normal(shape).astype(np.float32), 0, 1)
+        v, g = oracle.ssim(a, b)
+        v64, g64 = helpers.ssim_float64(a, b)
+        assert v == pytest.approx(v64, abs=2e-7)
+        assert np.abs(g - g64).max() <= 5e-6 * np.abs(g64).max()
+    # a constant offset lowers the luminance term only: ssim < 1 and finite gradients
+    v, g = oracle.ssim(np.full((1, 16, 16), 0.25, np.float32), np.full((1, 16, 16), 0.75, np.float32))
+    assert 0.0 < v < 1.0 and np.isfinite(g).all()
