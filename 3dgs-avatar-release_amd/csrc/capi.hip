@@ -186,6 +186,26 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     return GS_OK;
 }
 
+// Both phases in one call: the only host synchronisation of the forward (the pair count sizes the binning
+// state) is taken here, next to the launches that follow it, so the GPU idles only for the wake-up -- not
+// for the caller's interpreter as well.
+int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
+               size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color, int64_t* num_rendered,
+               void* stream) {
+    if (!count_host_pinned || !num_rendered) return GS_E_BAD_ARG;
+    int rc = gs_forward_preprocess(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned, stream);
+    if (rc != GS_OK) return rc;
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { gs_set_error((int)e, "count.sync"); return GS_E_HIP; }
+    const int64_t D = *count_host_pinned;
+    *num_rendered = D;
+    if (D > (int64_t)GS_MAX_PAIRS) return GS_E_TOO_LARGE;
+    const ImgLayout I = img_layout(a->W, a->H);
+    (void)I;
+    if (D > 0 && (!binning || binning_bytes < bin_layout(D).total)) return GS_E_WORKSPACE;  // caller sizes it, then phase 2
+    return gs_forward_render(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream);
+}
+
 int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,
                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t D, float* out_color,
                       void* stream) {

@@ -183,23 +183,28 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
                                                    img, color, dev)
             count = _pinned_count(dev)
-            _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), geom_bytes, img.data_ptr(), img_bytes,
-                                               radii.data_ptr(), count.data_ptr(), sptr))
-            # allocate for the expected pair count while phase 1 runs, so that only kernel launches are
-            # left to do once the count is known (the GPU idles between the sync and the first launch)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
+            # previous frame's count (+ 1/8) is handed to gs_forward, which takes the one host sync of the
+            # forward itself and launches phase 2 right behind it; only when the buffer turns out too small
+            # does control come back here to allocate and run phase 2 separately.
             guess = _last_count.get((dev.index, P, W, H), 0)
             bin_bytes = _lib.nbytes(L.gs_binning_bytes, guess + guess // 8, W, H) if guess else 0
             binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if guess else None
-            stream.synchronize()  # the one host sync of the forward: the size of the pair list
-            num_rendered = int(count.item())
-            _last_count[(dev.index, P, W, H)] = num_rendered
-            need = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
-            if binning is None or bin_bytes < need:
-                bin_bytes = need
+            nr = ctypes.c_int64(0)
+            rc = L.gs_forward(ctypes.byref(a), geom.data_ptr(), geom_bytes, _lib.ptr(binning), bin_bytes, img.data_ptr(),
+                              img_bytes, radii.data_ptr(), count.data_ptr(), color.data_ptr(), ctypes.byref(nr), sptr)
+            num_rendered = int(nr.value)
+            if rc == _lib.GS_E_WORKSPACE:
+                bin_bytes = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
                 binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
-                                           img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr))
+                rc = L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
+                                         img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr)
+            _lib.check(rc)
+            _last_count[(dev.index, P, W, H)] = num_rendered
+            if binning is None:  # nothing visible on the first call for this shape
+                binning = torch.empty(0, dtype=torch.uint8, device=dev)
+                bin_bytes = 0
             if _SHARE:
                 _geom_cache.store(dev, gkey, geom=geom, binning=binning, img=img, num_rendered=num_rendered, radii=radii)
         return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,

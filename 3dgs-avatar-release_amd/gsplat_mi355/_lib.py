@@ -26,10 +26,12 @@ class GsGrads(ctypes.Structure):
 
 
 EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_scratch_bytes",
-           "gs_forward_preprocess", "gs_forward_render", "gs_forward_shared", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
+           "gs_forward_preprocess", "gs_forward_render", "gs_forward", "gs_forward_shared", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward"]
+
+GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 
 _lock = threading.Lock()
 _lib = None
@@ -56,6 +58,8 @@ def load():
                                             c_void_p, c_void_p]
         L.gs_forward_render.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
                                         c_int64, c_void_p, c_void_p]
+        L.gs_forward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                                 c_void_p, c_void_p, POINTER(c_int64), c_void_p]
         L.gs_forward_shared.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                         c_void_p, c_size_t, c_int64, c_void_p, c_void_p]
         L.gs_backward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,

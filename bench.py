@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--loss", default="l1", choices=["l1", "l1+dssim"],
+                    help="l1 = the BASELINE metric's loss; l1+dssim = 0.8 L1 + 0.2 (1 - SSIM), the reference's full image loss")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -77,7 +79,7 @@ def main():
 
     from gsplat_mi355 import _lib
     from gsplat_mi355.camera import orbit_camera
-    from gsplat_mi355.render import Pipe, l1_loss, render
+    from gsplat_mi355.render import Pipe, l1_loss, render, ssim
     from gsplat_mi355.scenes import GaussianCloud, synthetic_cloud
     from gsplat_mi355.sharding import broadcast_cloud, frames_of_rank
 
@@ -109,6 +111,8 @@ def main():
         if do_bwd:
             pkg = render(cams[i], cloud, pipe, bg)
             loss = l1_loss(pkg.render, gt)
+            if args.loss == "l1+dssim":  # train.py:120-124 with lambda_l1 = 0.8, lambda_dssim = 0.2
+                loss = 0.8 * loss + 0.2 * (1.0 - ssim(pkg.render, gt))
             loss.backward()
         else:
             with torch.no_grad():
@@ -179,8 +183,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, L1 loss" % (
-                args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward"),
+            "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
+                args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
+                "L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss"),
                 "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
                 "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
                 "broadcast_s": round(t_bcast, 6)},

@@ -101,6 +101,15 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                       void* img, size_t img_bytes, int64_t num_rendered, float* out_color, void* stream);
 
+/* ---- forward, both phases in one call (the whole of upstream rasterize_gaussians).  Runs phase 1, waits on
+ * `stream` for the pair count (the one host synchronisation of the forward), stores it in *num_rendered and,
+ * if `binning_bytes` >= gs_binning_bytes(*num_rendered), goes straight on with phase 2.  Otherwise returns
+ * GS_E_WORKSPACE with *num_rendered set: the caller allocates the binning state and calls gs_forward_render.
+ * Callers pass a binning buffer sized from the previous frame's count so that the second case is rare. */
+int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
+               size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color, int64_t* num_rendered,
+               void* stream);
+
 /* ---- shared-geometry forward (no upstream counterpart).  The reference's render()
  * rasterizes twice per step with identical geometry -- colour pass, then an opacity pass with
  * colors = 1 (gaussian_renderer/__init__.py:121-142).  Given the geom / binning / image state of a
