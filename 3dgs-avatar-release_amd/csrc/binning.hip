@@ -39,7 +39,8 @@ __global__ __launch_bounds__(SC_THREADS) void scan_reduce_kernel(const uint32_t*
 
 // pass 2: exclusive scan of the block sums (one workgroup), total -> count
 __global__ __launch_bounds__(1024) void scan_bsum_kernel(uint32_t* __restrict__ bsum, int nblk,
-                                                         unsigned long long* __restrict__ count) {
+                                                         unsigned long long* __restrict__ count,
+                                                         unsigned long long* host_count) {
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(1024) void scan_bsum_kernel(uint32_t* __restrict__ 
         if (tid == 0) carry_s = carry + total;
         __syncthreads();
     }
-    if (tid == 0) count[0] = carry_s;  // 64-bit total: overflow of the 32-bit index space is detectable
+    if (tid == 0) {
+        count[0] = carry_s;  // 64-bit total: overflow of the 32-bit index space is detectable
+        // ... and straight into the caller's pinned host word, which the host is polling: the pair count
+        // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
+        if (host_count) __hip_atomic_store(host_count, carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // pass 3: per-block exclusive scan + block base
@@ -103,11 +109,12 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* 
 }
 
 int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
-                      uint32_t* bsum, unsigned long long* count, int P, int debug, hipStream_t s) {
+                      uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
+                      hipStream_t s) {
     const int nblk = (P + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, sorted_idx, tiles, tt_rank, bsum, P);
     GS_LAUNCH_CHECK("scan.reduce", debug, s);
-    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, count);
+    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, count, host_count);
     GS_LAUNCH_CHECK("scan.bsum", debug, s);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, tt_rank, bsum, offs, P);
     GS_LAUNCH_CHECK("scan.apply", debug, s);

@@ -28,6 +28,7 @@ struct ProfState {
 };
 // process-wide (autograd runs the backward on its own host thread), guarded by a mutex
 #include <mutex>
+#include <chrono>
 static ProfState g_prof;
 static std::mutex g_prof_mu;
 void gs_prof_begin(const char* stage, hipStream_t s) {
@@ -89,8 +90,9 @@ int gs_backward_scratch_bytes(int64_t D, int32_t P, int32_t W, int32_t H, size_t
     return GS_OK;
 }
 
-int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes,
-                          int32_t* radii, int64_t* count_host_pinned, void* stream) {
+// `poll`: a pinned host word the scan kernel writes the count into directly (gs_forward spins on it)
+static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes, int32_t* radii,
+                          int64_t* count_host_pinned, unsigned long long* poll, void* stream) {
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom || !img || (a->P > 0 && !radii)) return GS_E_BAD_ARG;
@@ -119,14 +121,19 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         // 4 passes -> the sorted index ends in (k0, v0)
         { StageScope sc_("scan", s);
         rc = launch_scan_tiles(v0, (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.tt_rank), (uint32_t*)(g + L.offs),
-                               (uint32_t*)(g + L.bsum), count, a->P, a->debug, s); }
+                               (uint32_t*)(g + L.bsum), count, poll, a->P, a->debug, s); }
         if (rc != GS_OK) return rc;
     }
-    if (count_host_pinned) {
+    if (count_host_pinned && (!poll || a->P == 0)) {
         hipError_t e = hipMemcpyAsync(count_host_pinned, count, 8, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) { gs_set_error((int)e, "count.copy"); return GS_E_HIP; }
     }
     return GS_OK;
+}
+
+int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes,
+                          int32_t* radii, int64_t* count_host_pinned, void* stream) {
+    return forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned, nullptr, stream);
 }
 
 int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
@@ -193,11 +200,30 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
                size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color, int64_t* num_rendered,
                void* stream) {
     if (!count_host_pinned || !num_rendered) return GS_E_BAD_ARG;
-    int rc = gs_forward_preprocess(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned, stream);
+    // The scan kernel stores the count into the pinned word itself and the host polls it: the count arrives a
+    // PCIe write after it exists.  (A copy + hipStreamSynchronize costs ~20 us of wake-up during which the GPU
+    // idles.)  The poll is bounded; past the bound, or without Gaussians, the stream is synchronised instead.
+    volatile int64_t* word = count_host_pinned;
+    const int64_t pending = -1;
+    const bool poll = a && a->P > 0;
+    if (poll) *word = pending;
+    int rc = forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned,
+                            poll ? (unsigned long long*)count_host_pinned : nullptr, stream);
     if (rc != GS_OK) return rc;
-    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) { gs_set_error((int)e, "count.sync"); return GS_E_HIP; }
-    const int64_t D = *count_host_pinned;
+    bool have = false;
+    if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spin = 0;; spin++) {
+            if (*word != pending) { have = true; break; }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    if (!have) {
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { gs_set_error((int)e, "count.sync"); return GS_E_HIP; }
+        if (poll && *word == pending) { gs_set_error(0, "count.poll"); return GS_E_HIP; }
+    }
+    const int64_t D = *word;
     *num_rendered = D;
     if (D > (int64_t)GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const ImgLayout I = img_layout(a->W, a->H);

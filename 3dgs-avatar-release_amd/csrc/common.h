@@ -139,7 +139,8 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, ui
                       int debug, hipStream_t s);
 
 int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
-                      uint32_t* bsum, unsigned long long* count, int P, int debug, hipStream_t s);
+                      uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
+                      hipStream_t s);
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
                 uint32_t* vals, uint32_t* owner, int P, int64_t D, int gx, int debug, hipStream_t s);
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
