@@ -1,27 +1,33 @@
 // render_bwd.hip -- backward of the per-tile compositing (replaces upstream
 // renderCUDA backward and its 9 float atomicAdds per (pixel, Gaussian) pair).
 //
-// CDNA4 formulation -- GAUSSIAN-PARALLEL, no cross-lane reduction and no atomics at all:
+// CDNA4 formulation -- GAUSSIAN-PARALLEL, no atomics at all:
 //  * One wave64 per 8x8 quadrant.  The forward recorded the quadrant's compacted list (qlist) of the
 //    Gaussians whose footprint reaches it, up to its last contributor.
-//  * LANES ARE LIST ENTRIES, the 64 pixels stream through them.  Entry e lives in lane e mod 64 for the
-//    64 steps e .. e+63; at step s that lane works on pixel s - e.  A pixel's running state (T, Pfx)
-//    therefore moves one lane per step -- a wave rotate (DPP wave_ror:1) -- and visits the entries
-//    front to back, exactly like the forward.  Each lane keeps its Gaussian's nine gradient sums
-//    in registers over its 64 pixels.  The pipeline is skewed, so it never drains between chunks of
-//    64 entries: only the first 63 steps of a quadrant run partly empty.
+//  * LANES ARE LIST ENTRIES, the pixels stream through them.  The wave is FOUR RINGS of 16 lanes (the
+//    rows DPP row_ror:1 rotates); ring r owns 16 of the 64 pixels and all four rings hold the same 16
+//    entries: entry e sits at position e mod 16 of every ring for the 16 steps e .. e+15, and at step s
+//    works on the pixel at ring position s - e.  A pixel's running state (T and the not yet composited
+//    part of Gtot) therefore moves one lane per step and visits the entries front to back, exactly like
+//    the forward.  The pipeline is skewed, so it never drains between chunks of 16 entries ("rounds"):
+//    only the first and last 15 steps of a quadrant run partly empty (a single 64-lane ring wasted 63
+//    steps per quadrant, 22 % of all steps on the benchmark scene).
 //    (The pixel-parallel formulation needs a 64-lane reduction of nine values per list entry; DPP
 //    adds issue at half rate on gfx950 (tools/dpp_rate.hip), which made that reduction ~2/3 of the
 //    kernel.)
-//  * Entries never touch LDS: every lane gathers the record of its entry of chunk c+2 while chunk
-//    c runs (two register sets), converts it at the round boundary, and at its own switch step
-//    (lane == step mod 64) selects it into the working set.  Per-pixel constants (dL/dpixel, Gtot,
-//    position, last contributor) sit in LDS and are read at the lane's current pixel index, one step
-//    ahead.  A lane that has seen all 64 pixels parks its nine sums in an LDS row; rows go to HBM
-//    64 at a time at the round boundary.
+//  * Entries never touch LDS: every lane gathers the record of its entry two chunks ahead, converts it
+//    at the round boundary, and at its own switch step (ring position == step mod 16) moves it into
+//    the working set.  Per-pixel constants (dL/dpixel, position, last-contributor limit) sit in LDS, one
+//    array per component, and are read at the lane's current pixel index one step ahead.
+//  * Each lane keeps TWO sets of nine gradient sums, named by the parity of the chunk they belong to:
+//    lanes that have switched in the current round add into one set, the others still into the other
+//    (the nine FMAs issued under complementary exec masks).  A set is complete for every lane one
+//    round later: it is folded over the four rings, stored by ring 0 and cleared at a round start --
+//    nothing is stored or cleared under a one-lane exec mask, where an instruction costs as much as
+//    with 64 lanes.
 //  * FRONT-to-back recurrence.  With g = dL/dpixel, Gtot = out_color . g (out_color already holds
-//    T_final * bg) and the running inclusive prefix Pfx_i = sum_{j<=i} (c_j . g) alpha_j T_j,
-//        dL/dalpha_i = T_i (c_i . g) - (Gtot - Pfx_i) / (1 - alpha_i)
+//    T_final * bg) and Rem_i = Gtot - sum_{j<=i} (c_j . g) alpha_j T_j,
+//        dL/dalpha_i = T_i (c_i . g) - Rem_i / (1 - alpha_i)
 //    which is the reference's back-to-front recurrence (accum_rec / T division) rewritten so that T is
 //    rebuilt by the same multiplications the forward did.
 //  * Output: the nine raw sums of (pair, quadrant) at row 4 pair + quadrant, pairs in EMISSION order
@@ -31,9 +37,11 @@
 #include "common.h"
 #include "blend.h"
 
-__device__ __forceinline__ float wave_ror1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xF, 0xF, true));
+// rotate by one lane inside every row of 16 lanes (DPP row_ror:1)
+__device__ __forceinline__ float ring_ror1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));
 }
+#define RING 16  // lanes per ring; a wave holds 64 / RING rings
 
 // x[0..8] += (Gd dx, Gd dy, tdx dx, tdx dy, tdy dy, Gd, wgt gx, wgt gy, wgt gz) on the lanes of `mask`,
 // y[0..8] += the same on all other lanes: the nine instructions issued twice under complementary exec
@@ -90,13 +98,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ dL_dpix,
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
-    // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step), each stored twice
-    // so a round's reads never wrap:  g0, g1, g2, x, y, lim
+    // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
+    // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row (32 words per ring) so a
+    // round's reads never wrap:  g0, g1, g2, x, y, lim
     __shared__ float pix[6][128];
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
+    const int j = lane & (RING - 1), ring = lane / RING;  // position in the ring / which ring
     const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
     const int px = QX0 + (lane & 7), py = QY0 + (lane >> 3);
     const uint2 range = ranges[tile];
@@ -107,22 +117,23 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float gtot0;  // Gtot of pixel `lane`
     {
-        // (g0, g1, g2, Gtot) and (x, y, lim): pixel p meets compacted entry k at step s = k + p, and the
-        // pair counts only while k < (its last contributor) <=> s < lim = ncon + p
-        float4 c0 = zero4, c1 = make_float4((float)px, (float)py, __uint_as_float((uint32_t)lane), 0.f);
+        // (g0, g1, g2, Gtot) and (x, y, lim): the pixel at position i of its ring meets compacted entry k at
+        // step s = k + i, and the pair counts only while k < (its last contributor) <=> s < lim = ncon + i
+        float4 c0 = zero4, c1 = make_float4((float)px, (float)py, __uint_as_float((uint32_t)j), 0.f);
         if (px < W && py < H) {
             const size_t HW = (size_t)H * W;
             const size_t pid = (size_t)py * W + px;
             const float g0 = dL_dpix[pid], g1 = dL_dpix[HW + pid], g2 = dL_dpix[2 * HW + pid];
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
-            c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)lane);
+            c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)j);
         }
-        pix[0][lane] = pix[0][64 + lane] = c0.x;
-        pix[1][lane] = pix[1][64 + lane] = c0.y;
-        pix[2][lane] = pix[2][64 + lane] = c0.z;
-        pix[3][lane] = pix[3][64 + lane] = c1.x;
-        pix[4][lane] = pix[4][64 + lane] = c1.y;
-        pix[5][lane] = pix[5][64 + lane] = c1.z;
+        const int slot = ring * 2 * RING + j;
+        pix[0][slot] = pix[0][slot + RING] = c0.x;
+        pix[1][slot] = pix[1][slot + RING] = c0.y;
+        pix[2][slot] = pix[2][slot + RING] = c0.z;
+        pix[3][slot] = pix[3][slot + RING] = c1.x;
+        pix[4][slot] = pix[4][slot + RING] = c1.y;
+        pix[5][slot] = pix[5][slot + RING] = c1.z;
         gtot0 = c0.w;
     }
 
@@ -149,9 +160,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
     Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
     uint32_t nxt_row = 0;  // gradient row (4 pair + quadrant) of the entry in `nxt`
-    gather(lane, p0, p1, p2);
-    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by lane t at step t
-    gather(64 + lane, p0, p1, p2);      // chunk 1 in flight during round 0
+    gather(j, p0, p1, p2);              // (the four rings hold the same entries)
+    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by position t of every ring at step t
+    gather(RING + j, p0, p1, p2);       // chunk 1 in flight during round 0
     __syncthreads();
 
     // Two accumulator sets, named by the PARITY of the chunk they belong to: during round R the lanes
@@ -164,14 +175,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 #pragma unroll
     for (int c9 = 0; c9 < 9; c9++) accA[c9] = accB[c9] = 0.f;
     uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
-    // index into pix[c][] of the pixel at this lane: (s - lane) mod 64, + 64 within a round
-    uint32_t pidx = (uint32_t)((64 - lane) & 63);
+    // index into pix[c][] of the pixel at this lane: ring base + (s - j) mod 16, + 16 within a round
+    uint32_t pidx = (uint32_t)(ring * 2 * RING + ((RING - j) & (RING - 1)));
     float pc[6];
 #pragma unroll
     for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
-    // (pixel p starts at lane (64 - p) mod 64; fetch its Gtot from the lane that loaded it)
-    float T = 1.0f, Rem = __shfl(gtot0, (int)pidx, 64);
+    // (position i of a ring starts at ring lane (16 - i) mod 16; fetch its Gtot from the lane that loaded it)
+    float T = 1.0f, Rem = __shfl(gtot0, ring * RING + ((RING - j) & (RING - 1)), 64);
 
     // A finished entry's nine RAW sums go to its row in HBM.  What is constant per Gaussian -- opacity,
     // the conic combination of the two first moments, the -1/2 and 1/log2(e) factors -- is applied once
@@ -182,27 +193,38 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         q8[row] = __float_as_uint(a[8]);  // the ninth sum doubles as the "row written" mark
     };
 
-    // An entry k lives in its lane for the steps k .. k+63; the loop runs s = 0 .. m+62, so every entry
-    // k <= m-2 has seen all its pixels when the loop ends and entry m-1 has seen all pixels that reach it.
-    const int total = m + 63;
+    // An entry k lives at position k mod 16 of every ring for the steps k .. k+15; the loop runs
+    // s = 0 .. m+14, so every entry has seen all its pixels when the loop ends.
+    const int total = m + RING - 1;
+    // the four rings hold partial sums of the same entries: fold them (every lane ends with the total)
+    auto fold_rings = [&](float (&a)[9]) {
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) {
+            a[c9] += __shfl_xor(a[c9], 16, 64);
+            a[c9] += __shfl_xor(a[c9], 32, 64);
+        }
+    };
     auto run_round = [&](const int s0, float (&X)[9], uint32_t& rowX, float (&Y)[9]) {
         if (s0 > 0) {
             // round start: every lane took its entry of the previous chunk out of `nxt` during the
             // previous round.  X holds the finished sums of the chunk before that one: store them.  The
             // chunk that was in flight -> `nxt`; the chunk after it -> in flight.
-            if (s0 >= 128) write_row(rowX, X);
+            if (s0 >= 2 * RING) {
+                fold_rings(X);
+                if (ring == 0) write_row(rowX, X);
+            }
             convert(p0, p1, p2, nxt, nxt_row);
-            gather(s0 + 64 + lane, p0, p1, p2);
-            pidx -= 64u;
+            gather(s0 + RING + j, p0, p1, p2);
+            pidx -= (uint32_t)RING;
         }
         rowX = nxt_row;
 #pragma unroll
         for (int c9 = 0; c9 < 9; c9++) X[c9] = 0.f;
-        const int tend = min(64, total - s0);
-        unsigned long long mx = 1ull;  // lanes <= t, kept up to date step by step
+        const int tend = min(RING, total - s0);
+        unsigned long long mx = 0x0001000100010001ull;  // ring positions <= t, kept up to date step by step
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
-            if (lane == t) cur = nxt;  // this lane takes its entry of the new chunk
+            if (j == t) cur = nxt;  // position t of every ring takes its entry of the new chunk
             const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[3], pyf = pc[4];
             const uint32_t lim = __float_as_uint(pc[5]);
@@ -236,10 +258,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             //        6..8: w g_c = dL/dcolor     (t = Gd)
             // X += ... on the lanes <= t (they have taken their entry of this round's chunk), Y += ... on the others
             split_accumulate(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
-            mx = (mx << 1) | 1ull;
+            mx = (mx << 1) | 0x0001000100010001ull;
             // the pixel moves on to the next entry = the next lane
-            T = wave_ror1(T);
-            Rem = wave_ror1(Rem);
+            T = ring_ror1(T);
+            Rem = ring_ror1(Rem);
         };
         // two steps per trip: the one-step-ahead pixel constants alternate between two register sets
         int t = 0;
@@ -249,18 +271,21 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         }
         if (t < tend) step(t);
     };
-    for (int s0 = 0; s0 < total; s0 += 128) {
+    for (int s0 = 0; s0 < total; s0 += 2 * RING) {
         run_round(s0, accA, rowA, accB);
-        if (s0 + 64 < total) run_round(s0 + 64, accB, rowB, accA);
+        if (s0 + RING < total) run_round(s0 + RING, accB, rowB, accA);
     }
     {
-        // the two chunks still in the sets: the one taken during the last round (only entry m-1 can be in
-        // it) and the one before it (complete for the lanes that switched, and holding entry m-1 otherwise)
-        const int last_round = (total - 1) >> 6;
+        // the two chunks still in the sets: the one taken during the last round and the one before it
+        const int last_round = (total - 1) / RING;
         const bool odd = last_round & 1;
-        const int k_new = 64 * last_round + lane, k_old = k_new - 64;
-        if (k_new <= m - 1) write_row(odd ? rowB : rowA, odd ? accB : accA);
-        if (last_round >= 1 && k_old <= m - 1) write_row(odd ? rowA : rowB, odd ? accA : accB);
+        const int k_new = RING * last_round + j, k_old = k_new - RING;
+        fold_rings(accA);
+        fold_rings(accB);
+        if (ring == 0) {
+            if (k_new <= m - 1) write_row(odd ? rowB : rowA, odd ? accB : accA);
+            if (last_round >= 1 && k_old <= m - 1) write_row(odd ? rowA : rowB, odd ? accA : accB);
+        }
     }
 }
 
