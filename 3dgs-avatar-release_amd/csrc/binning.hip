@@ -37,51 +37,21 @@ __global__ __launch_bounds__(SC_THREADS) void scan_reduce_kernel(const uint32_t*
     if (tid == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// pass 2: exclusive scan of the block sums (one workgroup), total -> count
-__global__ __launch_bounds__(1024) void scan_bsum_kernel(uint32_t* __restrict__ bsum, int nblk,
-                                                         unsigned long long* __restrict__ count,
-                                                         unsigned long long* host_count) {
-    __shared__ uint32_t wsum[16];
-    __shared__ unsigned long long carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = i < nblk ? bsum[i] : 0u;
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-        for (int w = 0; w < 16; w++) {
-            if (w < wid) woff += wsum[w];
-            total += wsum[w];
-        }
-        const unsigned long long carry = carry_s;
-        if (i < nblk) bsum[i] = (uint32_t)(carry + woff + x - v);
-        __syncthreads();
-        if (tid == 0) carry_s = carry + total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        count[0] = carry_s;  // 64-bit total: overflow of the 32-bit index space is detectable
-        // ... and straight into the caller's pinned host word, which the host is polling: the pair count
-        // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
-        if (host_count) __hip_atomic_store(host_count, carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// pass 3: per-block exclusive scan + block base
+// pass 2: per-block exclusive scan; every block adds up the sums of the blocks before it itself (they
+// are few: P / 4096), the last block also publishes the grand total = the pair count
 __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ tt_rank,
                                                                 const uint32_t* __restrict__ bsum,
-                                                                uint32_t* __restrict__ offs, int P) {
+                                                                uint32_t* __restrict__ offs, int P,
+                                                                unsigned long long* __restrict__ count,
+                                                                unsigned long long* host_count) {
     __shared__ uint32_t ws[4];
+    __shared__ unsigned long long wb[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned long long before = 0;  // 64-bit: overflow of the 32-bit index space stays detectable in the count
+    for (int b = tid; b < (int)blockIdx.x; b += SC_THREADS) before += bsum[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    if (lane == 0) wb[wid] = before;
     const int base = blockIdx.x * SCAN_ITEMS + tid * SC_PER_THREAD;  // consecutive items per thread
     uint32_t v[SC_PER_THREAD];
     uint32_t tsum = 0;
@@ -98,13 +68,21 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* 
     }
     if (lane == 63) ws[wid] = x;
     __syncthreads();
+    const unsigned long long block_base = (wb[0] + wb[1]) + (wb[2] + wb[3]);
     uint32_t woff = 0;
     for (int w = 0; w < wid; w++) woff += ws[w];
-    uint32_t excl = bsum[blockIdx.x] + woff + x - tsum;
+    uint32_t excl = (uint32_t)block_base + woff + x - tsum;
 #pragma unroll
     for (int k = 0; k < SC_PER_THREAD; k++) {
         if (base + k < P) offs[base + k] = excl;
         excl += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const unsigned long long total = block_base + ws[0] + ws[1] + ws[2] + ws[3];
+        count[0] = total;
+        // ... and straight into the caller's pinned host word, which the host is polling: the pair count
+        // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
+        if (host_count) __hip_atomic_store(host_count, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -114,9 +92,7 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
     const int nblk = (P + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, sorted_idx, tiles, tt_rank, bsum, P);
     GS_LAUNCH_CHECK("scan.reduce", debug, s);
-    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, count, host_count);
-    GS_LAUNCH_CHECK("scan.bsum", debug, s);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, tt_rank, bsum, offs, P);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, tt_rank, bsum, offs, P, count, host_count);
     GS_LAUNCH_CHECK("scan.apply", debug, s);
     return GS_OK;
 }
@@ -133,7 +109,10 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
 // Stores are fully coalesced.
 __global__ __launch_bounds__(256) void emit_owner_kernel(const uint32_t* __restrict__ tt_rank,
                                                          const uint32_t* __restrict__ offs, int P, uint32_t D,
-                                                         uint32_t nchunks, uint32_t* __restrict__ owner) {
+                                                         uint32_t nchunks, uint32_t* __restrict__ owner, ZeroJob zero_a,
+                                                         ZeroJob zero_b) {
+    zero_job(zero_a);  // the tile sort's digit totals and the tile ranges (saves two fill launches)
+    zero_job(zero_b);
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P) return;
     const uint32_t tt = tt_rank[r];
@@ -188,11 +167,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
 }
 
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, int P, int64_t D, int gx, int debug, hipStream_t s) {
+                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, int64_t D, int gx, int debug,
+                hipStream_t s) {
     if (D <= 0) return GS_OK;
     const uint32_t nchunks = (uint32_t)((D + EMIT_CHUNK - 1) / EMIT_CHUNK);
     hipLaunchKernelGGL(emit_owner_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tt_rank, offs, P, (uint32_t)D, nchunks,
-                       owner);
+                       owner, zero_a, zero_b);
     GS_LAUNCH_CHECK("emit.owner", debug, s);
     hipLaunchKernelGGL(emit_kernel, dim3(nchunks), dim3(256), 0, s, sorted_idx, offs, owner, rec, keys, vals, (uint32_t)D,
                        nchunks, gx);
@@ -218,9 +198,12 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
     if (j == D - 1) ranges[2 * cur + 1] = (uint32_t)D;
 }
 
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
-    if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
+                  hipStream_t s) {
+    if (!ranges_zeroed) {
+        hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+    }
     if (D > 0) {
         hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, tile_sorted, ranges, D);
         GS_LAUNCH_CHECK("ranges", debug, s);

@@ -110,13 +110,15 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         uint32_t* k1 = (uint32_t*)(g + L.key1);
         uint32_t* v0 = (uint32_t*)(g + L.val0);
         uint32_t* v1 = (uint32_t*)(g + L.val1);
+        ZeroJob zt;  // the depth sort's digit totals, cleared by the preprocess kernel
+        sort_totals_region((uint32_t*)(g + L.hist), a->P, 32, &zt.ptr, &zt.words);
         { StageScope sc_("preprocess", s);
         rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
-                               (uint32_t*)(g + L.clamped), k0, v0, radii, s); }
+                               (uint32_t*)(g + L.clamped), k0, v0, radii, zt, s); }
         if (rc != GS_OK) return rc;
         // stable sort by depth bits: ties keep ascending Gaussian index (the reference's tie order)
         { StageScope sc_("depth_sort", s);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, a->debug, s); }
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s); }
         if (rc != GS_OK) return rc;
         // 4 passes -> the sorted index ends in (k0, v0)
         { StageScope sc_("scan", s);
@@ -158,18 +160,22 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
         uint32_t* k1 = (uint32_t*)(b + B.key1);
         uint32_t* v0 = (uint32_t*)(b + B.val0);
         uint32_t* v1 = (uint32_t*)(b + B.val1);
+        const int bits = tile_bits(ntiles);
+        ZeroJob zt, zr;  // the tile sort's digit totals and the tile ranges, cleared by the emission pre-pass
+        sort_totals_region((uint32_t*)(b + B.hist), D, bits, &zt.ptr, &zt.words);
+        zr.ptr = ranges;
+        zr.words = ntiles * 2;
         { StageScope sc_("emit", s);
         rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
-                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), a->P, D, I.gx, a->debug, s); }
+                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), zt, zr, a->P, D, I.gx, a->debug, s); }
         if (rc != GS_OK) return rc;
-        const int bits = tile_bits(ntiles);
         { StageScope sc_("tile_sort", s);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, a->debug, s); }
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, true, a->debug, s); }
         if (rc != GS_OK) return rc;
         const bool odd = radix_passes(bits) & 1;
         point_list = odd ? v1 : v0;
         { StageScope sc_("ranges", s);
-        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, a->debug, s); }
+        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, true, a->debug, s); }
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);

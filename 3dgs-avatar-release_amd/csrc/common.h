@@ -118,6 +118,12 @@ void gs_set_error(int hip_err, const char* stage);
 // Per-stage hipEvent timing (gs_profile_enable / gs_profile_collect); a no-op unless enabled.
 void gs_prof_begin(const char* stage, hipStream_t s);
 void gs_prof_end(hipStream_t s);
+// a word range some kernel clears on the side (grid-stride), saving a fill launch
+struct ZeroJob { uint32_t* ptr; int words; };
+__device__ __forceinline__ void zero_job(const ZeroJob z) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;
+}
+
 struct StageScope {
     hipStream_t s;
     StageScope(const char* stage, hipStream_t st) : s(st) { gs_prof_begin(stage, st); }
@@ -128,22 +134,34 @@ struct StageScope {
 // Stage launchers (each enqueues on `s`, returns GS_OK / GS_E_HIP)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, hipStream_t s);
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, ZeroJob zero, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
-// (k0,v0) and (k1,v1); the result lands in buffer (passes & 1).  `hist` holds 256*nblk u32.
+// (k0,v0) and (k1,v1); the result lands in buffer (passes & 1).  `hist` is the table area of the layouts.
+// The per-pass digit totals inside it must be zero when the first pass starts: either the sort clears
+// them itself (a fill launch), or the caller has a kernel that runs before it clear the region
+// sort_totals_region() names (`totals_zeroed`).
 int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                      int debug, hipStream_t s);
+                      bool totals_zeroed, int debug, hipStream_t s);
+static inline void sort_totals_region(uint32_t* hist, int64_t n, int bits, uint32_t** ptr, int* words) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const size_t items = nn <= (size_t)SORT_SMALL_N ? 1024 : SORT_ITEMS;
+    *ptr = hist + (size_t)256 * ((nn + items - 1) / items);
+    *words = ((bits + 7) / 8) * SORT_TOTALS_REPL * 256;
+}
+
 
 int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
                       uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
                       hipStream_t s);
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, int P, int64_t D, int gx, int debug, hipStream_t s);
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, int debug, hipStream_t s);
+                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, int64_t D, int gx, int debug,
+                hipStream_t s);
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
+                  hipStream_t s);
 
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
 size_t l1_ws_bytes(int64_t n);

@@ -199,7 +199,7 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     hipLaunchKernelGGL(knn_minmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, P, points, mm);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, mm, k0, v0);
     GS_LAUNCH_CHECK("knn.morton", 0, s);
-    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, 30, 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, 30, false, 0, s);
     if (rc != GS_OK) return rc;
     const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp);

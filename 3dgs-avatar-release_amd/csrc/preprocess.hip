@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
-    uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii) {
+    uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii, ZeroJob zero) {
+    zero_job(zero);  // the depth sort's digit totals (saves a fill launch)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 }
 
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, hipStream_t s) {
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, ZeroJob zero, hipStream_t s) {
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
     const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
     const int blocks = (a.P + 255) / 256;
@@ -124,7 +125,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.scales,
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
-                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii);
+                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, zero);
     GS_LAUNCH_CHECK("preprocess", a.debug, s);
     return GS_OK;
 }

@@ -197,15 +197,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
 
 template <int RS_ROUNDS>
 static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                           int debug, hipStream_t s) {
+                           bool totals_zeroed, int debug, hipStream_t s) {
     const int items = RS_ROUNDS * RS_THREADS;
     const int nblk = (int)((n + items - 1) / items);
     const int passes = radix_passes(bits);
     const int dbits = 8;  // (an equal 6 + 6 split of 12 tile bits measured no faster than 8 + 4)
     // per-pass digit totals live behind the [256][nblk] table (the layouts reserve room for them)
     uint32_t* totals = hist + (size_t)256 * nblk;
-    hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * RS_REPL * 256 * 4, s);
-    if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
+    if (!totals_zeroed) {
+        hipError_t me = hipMemsetAsync(totals, 0, (size_t)passes * RS_REPL * 256 * 4, s);
+        if (me != hipSuccess) { gs_set_error((int)me, "sort.memset"); return GS_E_HIP; }
+    }
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
         const int shift = dbits * p;
@@ -225,9 +227,9 @@ static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
 }
 
 int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                      int debug, hipStream_t s) {
+                      bool totals_zeroed, int debug, hipStream_t s) {
     if (n <= 0) return GS_OK;
-    // SORT_SMALL_N and the table sizes in the layouts (common.h) go together
-    if (n <= SORT_SMALL_N) return sort_pairs_impl<RS_ROUNDS_SMALL>(k0, v0, k1, v1, hist, n, bits, debug, s);
-    return sort_pairs_impl<RS_ROUNDS_BIG>(k0, v0, k1, v1, hist, n, bits, debug, s);
+    // SORT_SMALL_N and the table sizes in the layouts (common.h: sort_table_words, sort_totals_region) go together
+    if (n <= SORT_SMALL_N) return sort_pairs_impl<RS_ROUNDS_SMALL>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s);
+    return sort_pairs_impl<RS_ROUNDS_BIG>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s);
 }
