@@ -354,6 +354,39 @@ int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, s
     return launch_knn(P, points, mean_d2, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int gs_build_covariance(int32_t N, const float* scaling, float scaling_modifier, const float* rotation, int32_t rotation_is_matrix,
+                        float* cov6, void* stream) {
+    if (N < 0 || (N > 0 && (!scaling || !rotation || !cov6))) return GS_E_BAD_ARG;
+    if (!rotation_is_matrix && ((uintptr_t)rotation & 15u)) return GS_E_BAD_ARG;  // quaternions are read as float4
+    if (N == 0) return GS_OK;
+    return launch_build_cov(N, scaling, scaling_modifier, rotation, rotation_is_matrix ? 1 : 0, cov6, (hipStream_t)stream);
+}
+int gs_build_covariance_backward(int32_t N, const float* scaling, float scaling_modifier, const float* rotation,
+                                 int32_t rotation_is_matrix, const float* dL_dcov6, float* dL_dscaling, float* dL_drotation,
+                                 void* stream) {
+    if (N < 0 || (N > 0 && (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation))) return GS_E_BAD_ARG;
+    if (!rotation_is_matrix && (((uintptr_t)rotation | (uintptr_t)dL_drotation) & 15u)) return GS_E_BAD_ARG;
+    if (N == 0) return GS_OK;
+    return launch_build_cov_bwd(N, scaling, scaling_modifier, rotation, rotation_is_matrix ? 1 : 0, dL_dcov6, dL_dscaling,
+                                dL_drotation, (hipStream_t)stream);
+}
+int gs_sh2rgb(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
+              const float* fwd_rotation, const float* view_noise_host, float* colors, uint8_t* clamped, void* stream) {
+    if (N < 0 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) return GS_E_BAD_ARG;
+    if (N > 0 && (!shs || !xyz || !campos || !colors || !clamped)) return GS_E_BAD_ARG;
+    if (N == 0) return GS_OK;
+    return launch_sh2rgb(N, sh_degree, M, shs, xyz, campos, fwd_rotation, view_noise_host, colors, clamped, (hipStream_t)stream);
+}
+int gs_sh2rgb_backward(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
+                       const float* fwd_rotation, const float* view_noise_host, const uint8_t* clamped,
+                       const float* dL_dcolors, float* dL_dshs, float* dL_dxyz, void* stream) {
+    if (N < 0 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) return GS_E_BAD_ARG;
+    if (N > 0 && (!shs || !xyz || !campos || !clamped || !dL_dcolors || !dL_dshs || !dL_dxyz)) return GS_E_BAD_ARG;
+    if (N == 0) return GS_OK;
+    return launch_sh2rgb_bwd(N, sh_degree, M, shs, xyz, campos, fwd_rotation, view_noise_host, clamped, dL_dcolors, dL_dshs,
+                             dL_dxyz, (hipStream_t)stream);
+}
+
 int gs_l1_loss_workspace_bytes(int64_t n, size_t* out) {
     if (!out || n < 0) return GS_E_BAD_ARG;
     *out = l1_ws_bytes(n);

@@ -163,6 +163,16 @@ int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint3
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
                   hipStream_t s);
 
+// pre-rasterizer per-Gaussian chains (prepass.hip, row N3)
+int launch_build_cov(int N, const float* scales, float mod, const float* rot, int is_matrix, float* cov6, hipStream_t s);
+int launch_build_cov_bwd(int N, const float* scales, float mod, const float* rot, int is_matrix, const float* dL_dcov6,
+                         float* dL_dscales, float* dL_drot, hipStream_t s);
+int launch_sh2rgb(int N, int deg, int M, const float* shs, const float* xyz, const float* campos, const float* R_fwd,
+                  const float* noise_host, float* colors, uint8_t* clamped, hipStream_t s);
+int launch_sh2rgb_bwd(int N, int deg, int M, const float* shs, const float* xyz, const float* campos, const float* R_fwd,
+                      const float* noise_host, const uint8_t* clamped, const float* dL_dcolors, float* dL_dshs, float* dL_dxyz,
+                      hipStream_t s);
+
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
 size_t l1_ws_bytes(int64_t n);
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);

@@ -86,13 +86,10 @@ __device__ __forceinline__ void cov2d(const float3 mean, float fx, float fy, flo
     ratios[0] = txtz; ratios[1] = tytz;
 }
 
-// SH -> RGB (utils/sh_utils.py:58-101 polynomial; +0.5; clamp at 0 recorded as bit c of *clamped).
-// sh points at this Gaussian's (M,3) block.
-__device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 mean, const float3 campos, const float* __restrict__ sh,
-                                            uint32_t* clamped) {
-    const float dx = mean.x - campos.x, dy = mean.y - campos.y, dz = mean.z - campos.z;
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float x = dx / len, y = dy / len, z = dz / len;
+// SH -> RGB for a UNIT direction (x, y, z) (utils/sh_utils.py:58-101 polynomial; +0.5; clamp at 0 recorded
+// as bit c of *clamped).  sh points at this Gaussian's (M,3) block.
+__device__ __forceinline__ float3 sh_eval_dir(int deg, const float x, const float y, const float z,
+                                              const float* __restrict__ sh, uint32_t* clamped) {
     float out[3];
     uint32_t cl = 0;
 #pragma unroll
@@ -121,6 +118,14 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 mean, const fl
     }
     *clamped = cl;
     return make_float3(out[0], out[1], out[2]);
+}
+
+// SH -> RGB seen from campos (the rasterizer's own conversion: direction = (mean - campos) / |mean - campos|)
+__device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 mean, const float3 campos, const float* __restrict__ sh,
+                                            uint32_t* clamped) {
+    const float dx = mean.x - campos.x, dy = mean.y - campos.y, dz = mean.z - campos.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    return sh_eval_dir(deg, dx / len, dy / len, dz / len, sh, clamped);
 }
 
 // ---- SH tiles: the (M,3) coefficient block of Gaussian i is 3M contiguous floats, so a thread-per-

@@ -137,6 +137,30 @@ int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
 int knn_workspace_bytes(int32_t P, size_t* out);
 int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- pre-rasterizer per-Gaussian chains.
+ * gs_build_covariance: scene/gaussian_model.py:28-32 build_covariance_from_scaling_rotation =
+ *   strip_symmetric(L L^T), L = R diag(scaling_modifier * scaling) (utils/general_utils.py:73-85,194-207);
+ *   `rotation` is N quaternions (w,x,y,z), normalised as build_rotation does (general_utils.py:87-108), or,
+ *   with rotation_is_matrix, N row-major 3x3 matrices (the rigid deformer's rotation_precomp,
+ *   models/deformer/rigid.py:229-231).  cov6 = [xx, xy, xz, yy, yz, zz].  The backward gives what autograd
+ *   derives for that chain (d/dscaling, d/drotation in the input's own parametrisation).
+ * gs_sh2rgb: models/texture/texture.py:21-38 SH2RGB.forward: direction xyz - campos, optionally rotated by the
+ *   transpose of fwd_rotation[N,3,3] (cano_view_dir: T_fwd[:, :3, :3]) and multiplied from the right by a 3x3
+ *   view-noise matrix given as 9 HOST floats (NULL = none), normalised with +1e-12, eval_sh of degree
+ *   sh_degree over shs[N,M,3], +0.5, clamp at 0.  `clamped` (N bytes, bit c = channel c clamped) feeds the
+ *   backward, which returns d/dshs and d/dxyz (fwd_rotation carries no gradient: it is detached upstream,
+ *   rigid.py:223). ---- */
+int gs_build_covariance(int32_t N, const float* scaling, float scaling_modifier, const float* rotation,
+                        int32_t rotation_is_matrix, float* cov6, void* stream);
+int gs_build_covariance_backward(int32_t N, const float* scaling, float scaling_modifier, const float* rotation,
+                                 int32_t rotation_is_matrix, const float* dL_dcov6, float* dL_dscaling,
+                                 float* dL_drotation, void* stream);
+int gs_sh2rgb(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
+              const float* fwd_rotation, const float* view_noise_host, float* colors, uint8_t* clamped, void* stream);
+int gs_sh2rgb_backward(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
+                       const float* fwd_rotation, const float* view_noise_host, const uint8_t* clamped,
+                       const float* dL_dcolors, float* dL_dshs, float* dL_dxyz, void* stream);
+
 /* ---- image-side L1 loss: the reference computes
  * torch.abs(network_output - gt).mean() (utils/loss_utils.py:21-22, called at train.py:121) and lets
  * autograd derive d(loss)/d(network_output).  One call here: loss[0] = mean |x - y| and

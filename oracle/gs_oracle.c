@@ -704,6 +704,164 @@ double or_ssim(int C, int H, int W, const float* img1, const float* img2, float*
     return total / (double)n;
 }
 
+/* ---- N3: the two per-Gaussian torch chains in front of the rasterizer, in double ---- */
+static void n3_rotation(const float* rot, int is_matrix, int i, double R[3][3], double q[4], double* norm) {
+    if (is_matrix) {
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) R[a][b] = rot[9 * (size_t)i + 3 * a + b];
+        q[0] = 1; q[1] = q[2] = q[3] = 0; *norm = 1;
+        return;
+    }
+    const float* r4 = rot + 4 * (size_t)i;  /* utils/general_utils.py:87-108: q = r / |r|, (w, x, y, z) */
+    const double n = sqrt((double)r4[0] * r4[0] + (double)r4[1] * r4[1] + (double)r4[2] * r4[2] + (double)r4[3] * r4[3]);
+    for (int k = 0; k < 4; k++) q[k] = r4[k] / n;
+    *norm = n;
+    const double r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1 - 2 * (y * y + z * z); R[0][1] = 2 * (x * y - r * z); R[0][2] = 2 * (x * z + r * y);
+    R[1][0] = 2 * (x * y + r * z); R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (y * z - r * x);
+    R[2][0] = 2 * (x * z - r * y); R[2][1] = 2 * (y * z + r * x); R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
+/* scene/gaussian_model.py:28-32: strip_symmetric(L L^T), L = R diag(mod * scaling) (general_utils.py:194-207).
+ * dL_dcov6 != NULL: also the gradients autograd derives (strip_symmetric reads the UPPER triangle). */
+int or_build_covariance(int N, const float* scaling, float mod, const float* rot, int is_matrix, float* cov6,
+                        const float* dL_dcov6, float* dL_dscaling, float* dL_drot) {
+    for (int i = 0; i < N; i++) {
+        double R[3][3], q[4], n;
+        n3_rotation(rot, is_matrix, i, R, q, &n);
+        const double s[3] = {(double)mod * scaling[3 * i], (double)mod * scaling[3 * i + 1], (double)mod * scaling[3 * i + 2]};
+        double L[3][3], S[3][3];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) L[a][b] = R[a][b] * s[b];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) S[a][b] = L[a][0] * L[b][0] + L[a][1] * L[b][1] + L[a][2] * L[b][2];
+        if (cov6) {
+            float* o = cov6 + 6 * (size_t)i;
+            o[0] = (float)S[0][0]; o[1] = (float)S[0][1]; o[2] = (float)S[0][2];
+            o[3] = (float)S[1][1]; o[4] = (float)S[1][2]; o[5] = (float)S[2][2];
+        }
+        if (!dL_dcov6) continue;
+        const float* g = dL_dcov6 + 6 * (size_t)i;
+        const double G[3][3] = {{g[0], g[1], g[2]}, {0, g[3], g[4]}, {0, 0, g[5]}};
+        double dLm[3][3], dR[3][3];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                double v = 0;
+                for (int k = 0; k < 3; k++) v += (G[a][k] + G[k][a]) * L[k][b];
+                dLm[a][b] = v;
+            }
+        for (int b = 0; b < 3; b++) {
+            double v = 0;
+            for (int a = 0; a < 3; a++) v += dLm[a][b] * R[a][b];
+            dL_dscaling[3 * (size_t)i + b] = (float)(mod * v);
+        }
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) dR[a][b] = dLm[a][b] * s[b];
+        if (is_matrix) {
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) dL_drot[9 * (size_t)i + 3 * a + b] = (float)dR[a][b];
+        } else {
+            const double r = q[0], x = q[1], y = q[2], z = q[3];
+            double gq[4];
+            gq[0] = 2 * z * (dR[1][0] - dR[0][1]) + 2 * y * (dR[0][2] - dR[2][0]) + 2 * x * (dR[2][1] - dR[1][2]);
+            gq[1] = 2 * y * (dR[0][1] + dR[1][0]) + 2 * z * (dR[0][2] + dR[2][0]) + 2 * r * (dR[2][1] - dR[1][2]) - 4 * x * (dR[2][2] + dR[1][1]);
+            gq[2] = 2 * x * (dR[0][1] + dR[1][0]) + 2 * r * (dR[0][2] - dR[2][0]) + 2 * z * (dR[2][1] + dR[1][2]) - 4 * y * (dR[2][2] + dR[0][0]);
+            gq[3] = 2 * r * (dR[1][0] - dR[0][1]) + 2 * x * (dR[0][2] + dR[2][0]) + 2 * y * (dR[2][1] + dR[1][2]) - 4 * z * (dR[1][1] + dR[0][0]);
+            const double dot = q[0] * gq[0] + q[1] * gq[1] + q[2] * gq[2] + q[3] * gq[3];
+            for (int k = 0; k < 4; k++) dL_drot[4 * (size_t)i + k] = (float)((gq[k] - q[k] * dot) / n);
+        }
+    }
+    return 0;
+}
+
+/* models/texture/texture.py:21-38 SH2RGB.forward (+ backward when dL_dcolors != NULL).  shs is (N, M, 3);
+ * R_fwd (N,3,3) or NULL; noise 3x3 or NULL (dir @ noise).  eval_sh as utils/sh_utils.py:58-101, in double. */
+int or_sh2rgb(int N, int deg, int M, const float* shs, const float* xyz, const float* campos, const float* R_fwd,
+              const float* noise, float* colors, uint8_t* clamped, const float* dL_dcolors, float* dL_dshs, float* dL_dxyz) {
+    const double C0 = 0.28209479177387814, C1 = 0.4886025119029199;
+    const double C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396};
+    const double C3[7] = {-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+                          -0.4570457994644658, 1.445305721320277, -0.5900435899266435};
+    for (int i = 0; i < N; i++) {
+        double v[3] = {(double)xyz[3 * i] - campos[0], (double)xyz[3 * i + 1] - campos[1], (double)xyz[3 * i + 2] - campos[2]};
+        if (R_fwd) {
+            const float* R = R_fwd + 9 * (size_t)i;
+            const double w[3] = {R[0] * v[0] + R[3] * v[1] + R[6] * v[2], R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+                                 R[2] * v[0] + R[5] * v[1] + R[8] * v[2]};
+            v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+        }
+        if (noise) {
+            const double w[3] = {v[0] * noise[0] + v[1] * noise[3] + v[2] * noise[6], v[0] * noise[1] + v[1] * noise[4] + v[2] * noise[7],
+                                 v[0] * noise[2] + v[1] * noise[5] + v[2] * noise[8]};
+            v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+        }
+        const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), inv = 1.0 / (len + 1e-12);
+        const double x = v[0] * inv, y = v[1] * inv, z = v[2] * inv;
+        const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        double basis[16] = {0}, dbx[16] = {0}, dby[16] = {0}, dbz[16] = {0};
+        basis[0] = C0;
+        if (deg > 0) {
+            basis[1] = -C1 * y; dby[1] = -C1;
+            basis[2] = C1 * z; dbz[2] = C1;
+            basis[3] = -C1 * x; dbx[3] = -C1;
+        }
+        if (deg > 1) {
+            basis[4] = C2[0] * xy; dbx[4] = C2[0] * y; dby[4] = C2[0] * x;
+            basis[5] = C2[1] * yz; dby[5] = C2[1] * z; dbz[5] = C2[1] * y;
+            basis[6] = C2[2] * (2 * zz - xx - yy); dbx[6] = C2[2] * -2 * x; dby[6] = C2[2] * -2 * y; dbz[6] = C2[2] * 4 * z;
+            basis[7] = C2[3] * xz; dbx[7] = C2[3] * z; dbz[7] = C2[3] * x;
+            basis[8] = C2[4] * (xx - yy); dbx[8] = C2[4] * 2 * x; dby[8] = C2[4] * -2 * y;
+        }
+        if (deg > 2) {
+            basis[9] = C3[0] * y * (3 * xx - yy); dbx[9] = C3[0] * 6 * xy; dby[9] = C3[0] * (3 * xx - 3 * yy);
+            basis[10] = C3[1] * xy * z; dbx[10] = C3[1] * yz; dby[10] = C3[1] * xz; dbz[10] = C3[1] * xy;
+            basis[11] = C3[2] * y * (4 * zz - xx - yy); dbx[11] = C3[2] * -2 * xy; dby[11] = C3[2] * (4 * zz - xx - 3 * yy); dbz[11] = C3[2] * 8 * yz;
+            basis[12] = C3[3] * z * (2 * zz - 3 * xx - 3 * yy); dbx[12] = C3[3] * -6 * xz; dby[12] = C3[3] * -6 * yz; dbz[12] = C3[3] * (6 * zz - 3 * xx - 3 * yy);
+            basis[13] = C3[4] * x * (4 * zz - xx - yy); dbx[13] = C3[4] * (4 * zz - 3 * xx - yy); dby[13] = C3[4] * -2 * xy; dbz[13] = C3[4] * 8 * xz;
+            basis[14] = C3[5] * z * (xx - yy); dbx[14] = C3[5] * 2 * xz; dby[14] = C3[5] * -2 * yz; dbz[14] = C3[5] * (xx - yy);
+            basis[15] = C3[6] * x * (xx - 3 * yy); dbx[15] = C3[6] * (3 * xx - 3 * yy); dby[15] = C3[6] * -6 * xy;
+        }
+        const int nb = (deg + 1) * (deg + 1);
+        const float* sh = shs + (size_t)i * M * 3;
+        double ddir[3] = {0, 0, 0};
+        uint8_t cl = 0;
+        for (int c = 0; c < 3; c++) {
+            double r = 0;
+            for (int k = 0; k < nb; k++) r += basis[k] * sh[k * 3 + c];
+            r += 0.5;
+            if (r < 0) cl |= (uint8_t)(1u << c);
+            if (colors) colors[3 * (size_t)i + c] = (float)(r < 0 ? 0 : r);
+            if (dL_dcolors) {
+                const double g = (r < 0) ? 0.0 : dL_dcolors[3 * (size_t)i + c];
+                for (int k = 0; k < M; k++) dL_dshs[((size_t)i * M + k) * 3 + c] = (float)(k < nb ? basis[k] * g : 0.0);
+                for (int k = 0; k < nb; k++) {
+                    ddir[0] += dbx[k] * sh[k * 3 + c] * g;
+                    ddir[1] += dby[k] * sh[k * 3 + c] * g;
+                    ddir[2] += dbz[k] * sh[k * 3 + c] * g;
+                }
+            }
+        }
+        if (clamped) clamped[i] = cl;
+        if (!dL_dcolors) continue;
+        const double dotv = v[0] * ddir[0] + v[1] * ddir[1] + v[2] * ddir[2];
+        const double k2 = len > 0 ? dotv * inv * inv / len : 0.0;
+        double gv[3] = {ddir[0] * inv - v[0] * k2, ddir[1] * inv - v[1] * k2, ddir[2] * inv - v[2] * k2};
+        if (noise) {
+            const double w[3] = {noise[0] * gv[0] + noise[1] * gv[1] + noise[2] * gv[2], noise[3] * gv[0] + noise[4] * gv[1] + noise[5] * gv[2],
+                                 noise[6] * gv[0] + noise[7] * gv[1] + noise[8] * gv[2]};
+            gv[0] = w[0]; gv[1] = w[1]; gv[2] = w[2];
+        }
+        if (R_fwd) {
+            const float* R = R_fwd + 9 * (size_t)i;
+            const double w[3] = {R[0] * gv[0] + R[1] * gv[1] + R[2] * gv[2], R[3] * gv[0] + R[4] * gv[1] + R[5] * gv[2],
+                                 R[6] * gv[0] + R[7] * gv[1] + R[8] * gv[2]};
+            gv[0] = w[0]; gv[1] = w[1]; gv[2] = w[2];
+        }
+        for (int k = 0; k < 3; k++) dL_dxyz[3 * (size_t)i + k] = (float)gv[k];
+    }
+    return 0;
+}
+
 void or_set_num_threads(int n) {
 #ifdef _OPENMP
     extern void omp_set_num_threads(int);

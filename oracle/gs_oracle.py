@@ -232,6 +232,44 @@ def ssim(img1, img2):
     return float(v), g
 
 
+def build_covariance(scaling, modifier, rotation, dL_dcov6=None):
+    """N3 restatement (scene/gaussian_model.py:28-32): cov6, and with dL_dcov6 also (d/dscaling, d/drotation)."""
+    sc = _f32(scaling).reshape(-1, 3)
+    rot = _f32(rotation)
+    is_matrix = rot.shape[-1] != 4
+    n = sc.shape[0]
+    cov = np.zeros((n, 6), np.float32)
+    if dL_dcov6 is None:
+        lib().or_build_covariance(c_int(n), _ptr(sc), c_float(modifier), _ptr(rot), c_int(int(is_matrix)), _ptr(cov), None, None, None)
+        return cov
+    g = _f32(dL_dcov6).reshape(n, 6)
+    ds, dr = np.zeros_like(sc), np.zeros_like(rot)
+    lib().or_build_covariance(c_int(n), _ptr(sc), c_float(modifier), _ptr(rot), c_int(int(is_matrix)), _ptr(cov), _ptr(g), _ptr(ds), _ptr(dr))
+    return cov, ds, dr
+
+
+def sh2rgb(features, xyz, campos, deg, fwd_rot=None, noise=None, dL_dcolors=None):
+    """N3 restatement (models/texture/texture.py:21-38): colours (+ clamped mask), and with dL_dcolors also
+    (d/dfeatures, d/dxyz).  features is (N, M, 3)."""
+    sh = _f32(features)
+    n, m = sh.shape[0], sh.shape[1]
+    p = _f32(xyz).reshape(n, 3)
+    cp = _f32(campos).reshape(3)
+    R = _f32(fwd_rot).reshape(n, 9) if fwd_rot is not None else None
+    nz = _f32(noise).reshape(9) if noise is not None else None
+    col = np.zeros((n, 3), np.float32)
+    cl = np.zeros(n, np.uint8)
+    if dL_dcolors is None:
+        lib().or_sh2rgb(c_int(n), c_int(deg), c_int(m), _ptr(sh), _ptr(p), _ptr(cp), _ptr(R) if R is not None else None,
+                        _ptr(nz) if nz is not None else None, _ptr(col), _ptr(cl), None, None, None)
+        return col, cl
+    g = _f32(dL_dcolors).reshape(n, 3)
+    dsh, dp = np.zeros_like(sh), np.zeros_like(p)
+    lib().or_sh2rgb(c_int(n), c_int(deg), c_int(m), _ptr(sh), _ptr(p), _ptr(cp), _ptr(R) if R is not None else None,
+                    _ptr(nz) if nz is not None else None, _ptr(col), _ptr(cl), _ptr(g), _ptr(dsh), _ptr(dp))
+    return col, cl, dsh, dp
+
+
 def set_num_threads(n):
     lib().or_set_num_threads(c_int(int(n)))
 

@@ -75,3 +75,61 @@ def ssim_float64(img1, img2):
     v = m.mean()
     v.backward()
     return float(v.detach()), a.grad[0].numpy()
+
+
+def covariance_float64(scaling, modifier, rotation, g6):
+    """Float64 torch restatement of scene/gaussian_model.py:28-32 (+ general_utils.py:73-108,194-207) with
+    autograd: returns (cov6, d/dscaling, d/drotation) for the upstream gradient g6."""
+    import torch
+    s = torch.from_numpy(np.asarray(scaling, np.float32)).double().requires_grad_(True)
+    r = torch.from_numpy(np.asarray(rotation, np.float32)).double().requires_grad_(True)
+    if r.shape[-1] == 4:
+        q = r / torch.sqrt((r * r).sum(1))[:, None]
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(-1, 3, 3)
+    else:
+        R = r
+    L = R @ torch.diag_embed(modifier * s)
+    S = L @ L.transpose(1, 2)
+    cov = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
+    (cov * torch.from_numpy(np.asarray(g6, np.float32)).double()).sum().backward()
+    return cov.detach().numpy(), s.grad.numpy(), r.grad.numpy()
+
+
+def sh2rgb_float64(features, xyz, campos, deg, fwd_rot, noise, g):
+    """Float64 torch restatement of models/texture/texture.py:21-38 with autograd (the SH polynomial written out
+    from utils/sh_utils.py:58-101): returns (colors, d/dfeatures, d/dxyz)."""
+    import torch
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+    C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435]
+    f = torch.from_numpy(np.asarray(features, np.float32)).double().requires_grad_(True)  # (N, M, 3)
+    p = torch.from_numpy(np.asarray(xyz, np.float32)).double().requires_grad_(True)
+    d = p - torch.from_numpy(np.asarray(campos, np.float32)).double()[None]
+    if fwd_rot is not None:
+        Rb = torch.from_numpy(np.asarray(fwd_rot, np.float32)).double().transpose(1, 2)
+        d = torch.matmul(Rb, d.unsqueeze(-1)).squeeze(-1)
+    if noise is not None:
+        d = torch.matmul(d, torch.from_numpy(np.asarray(noise, np.float32)).double())
+    u = d / (d.norm(dim=1, keepdim=True) + 1e-12)
+    x, y, z = u[:, 0:1], u[:, 1:2], u[:, 2:3]
+    sh = f.transpose(1, 2)  # (N, 3, M) as shs_view
+    res = C0 * sh[..., 0]
+    if deg > 0:
+        res = res - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] + C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] +
+               C2[3] * xz * sh[..., 7] + C2[4] * (xx - yy) * sh[..., 8])
+    if deg > 2:
+        res = (res + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10] +
+               C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
+               C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14] +
+               C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    col = torch.clamp_min(res + 0.5, 0.0)
+    (col * torch.from_numpy(np.asarray(g, np.float32)).double()).sum().backward()
+    gp = p.grad.numpy() if p.grad is not None else np.zeros(p.shape)  # degree 0 does not depend on the direction
+    return col.detach().numpy(), f.grad.numpy(), gp

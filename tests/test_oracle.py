@@ -297,3 +297,69 @@ def test_ssim_oracle_vs_float64_autograd_and_closed_forms(oracle):
     # a constant offset lowers the luminance term only: ssim < 1 and finite gradients
     v, g = oracle.ssim(np.full((1, 16, 16), 0.25, np.float32), np.full((1, 16, 16), 0.75, np.float32))
     assert 0.0 < v < 1.0 and np.isfinite(g).all()
+
+
+def _n3_inputs(n, seed, matrix):
+    rng = np.random.default_rng(seed)
+    scaling = np.exp(rng.normal(-3.0, 0.7, (n, 3))).astype(np.float32)
+    q = rng.normal(size=(n, 4)).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)  # not unit
+    if matrix:
+        # a rotation composed with a bone rotation, as rigid.py:229-230 builds rotation_precomp
+        import torch
+        qq = q / np.linalg.norm(q, axis=1, keepdims=True)
+        w, x, y, z = qq.T
+        R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                      1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                      1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3).astype(np.float32)
+        rot = R
+    else:
+        rot = q
+    g6 = rng.normal(size=(n, 6)).astype(np.float32)
+    return scaling, rot, g6
+
+
+@pytest.mark.parametrize("matrix", [False, True])
+def test_build_covariance_oracle_vs_float64_autograd(oracle, matrix):
+    """N3 oracle: strip_symmetric(L L^T) and the gradients autograd derives (upper-triangle read), for quaternion
+    and rotation_precomp inputs; closed form for the identity rotation."""
+    scaling, rot, g6 = _n3_inputs(300, 5, matrix)
+    cov, ds, dr = oracle.build_covariance(scaling, 1.7, rot, g6)
+    cov64, ds64, dr64 = helpers.covariance_float64(scaling, 1.7, rot, g6)
+    assert np.abs(cov - cov64).max() <= 1e-6 * np.abs(cov64).max()
+    assert np.abs(ds - ds64).max() <= 1e-6 * np.abs(ds64).max()
+    assert np.abs(dr - dr64).max() <= 1e-6 * np.abs(dr64).max()
+    ident = np.tile(np.array([[2.0, 0, 0, 0]], np.float32), (4, 1))  # unnormalised identity quaternion
+    s = np.array([[1, 2, 3]] * 4, np.float32)
+    c = oracle.build_covariance(s, 0.5, ident)
+    assert np.allclose(c, [[0.25, 0, 0, 1.0, 0, 2.25]] * 4)
+
+
+def test_sh2rgb_oracle_vs_reference_golden_and_float64_autograd(oracle):
+    """N3 oracle: pinned by tests/golden/sh_eval.npz (the reference's own eval_sh + 0.5 + clamp, degrees 0..3) for
+    unit directions; the canonical-frame rotation, the view noise, the +1e-12 normalisation and all gradients
+    against a float64 autograd restatement."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sh_eval.npz"))
+    feats = np.ascontiguousarray(g["sh"].transpose(0, 2, 1)).astype(np.float32)  # reference [N, C, M] -> get_features [N, M, 3]
+    dirs = g["dirs"].astype(np.float32)
+    for deg in range(4):
+        col, cl = oracle.sh2rgb(feats, 3.0 * dirs, np.zeros(3, np.float32), deg)
+        want = g["color_deg%d" % deg]
+        assert np.abs(col - want).max() <= 2e-6
+        for c in range(3):
+            assert np.array_equal((cl >> c) & 1, ((g["eval_deg%d" % deg][:, c] + 0.5) < 0).astype(np.uint8))
+    rng = np.random.default_rng(21)
+    n = 200
+    feats = (0.5 * rng.normal(size=(n, 16, 3))).astype(np.float32)
+    xyz = rng.normal(size=(n, 3)).astype(np.float32)
+    campos = np.array([0.3, -0.2, 4.0], np.float32)
+    _, R, _ = _n3_inputs(n, 8, True)
+    th = 0.3
+    noise = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
+    gcol = rng.normal(size=(n, 3)).astype(np.float32)
+    for deg, rot, nz in [(3, R, noise), (2, R, None), (1, None, None), (0, None, noise)]:
+        col, cl, dsh, dp = oracle.sh2rgb(feats, xyz, campos, deg, rot, nz, gcol)
+        col64, dsh64, dp64 = helpers.sh2rgb_float64(feats, xyz, campos, deg, rot, nz, gcol)
+        assert np.abs(col - col64).max() <= 1e-6
+        assert np.abs(dsh - dsh64).max() <= 1e-6 * max(np.abs(dsh64).max(), 1e-30)
+        assert np.abs(dp - dp64).max() <= 1e-6 * max(np.abs(dp64).max(), 1e-30)
