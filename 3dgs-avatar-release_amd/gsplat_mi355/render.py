@@ -66,6 +66,12 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
         cov3D_precomp = pc.covariance6(scaling_modifier)
     else:
         scales, rotations = pc.scales, pc.rotations
+    if colors_precomp is None and pipe.convert_SHs_python:
+        # the reference's texture module (models/texture/texture.py:21-38), fused: colours from SHs seen from the
+        # camera centre, in the canonical frame when the cloud carries the deformer's forward transform
+        from .prepass import sh2rgb
+        colors_precomp = sh2rgb(pc.shs, xyz, data.camera_center, pc.sh_degree,
+                                fwd_transform=getattr(pc, "fwd_transform", None))
     shs = None if colors_precomp is not None else pc.shs
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations,

@@ -35,16 +35,12 @@ class GaussianCloud(object):
         return GaussianCloud(*[getattr(self, f).to(device) for f in self.FIELDS], self.sh_degree)
 
     def covariance6(self, scale_modifier=1.0):
-        """cov3D_precomp (N,6) = strip_symmetric((R S)(R S)^T): scene/gaussian_model.py:28-32,
-        utils/general_utils.py:73-108,194-207."""
-        q = self.rotations / self.rotations.norm(dim=1, keepdim=True)
-        r, x, y, z = q.unbind(1)
-        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
-        L = R * (scale_modifier * self.scales).unsqueeze(1)
-        S = L @ L.transpose(1, 2)
-        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).contiguous()
+        """cov3D_precomp (N,6) = strip_symmetric((R S)(R S)^T): GaussianModel.get_covariance
+        (scene/gaussian_model.py:154-157) -- with the deformer's `rotation_precomp` (N,3,3) when the cloud carries
+        one, else with the quaternions -- through the fused HIP op (gsplat_mi355.prepass, row N3)."""
+        from .prepass import build_covariance_from_scaling_rotation
+        rot = getattr(self, "rotation_precomp", None)
+        return build_covariance_from_scaling_rotation(self.scales, scale_modifier, rot if rot is not None else self.rotations)
 
     def pack(self):
         """One flat fp32 buffer [xyz | scales | rotations | opacity | shs]: the broadcast payload of

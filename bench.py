@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--loss", default="l1", choices=["l1", "l1+dssim"],
                     help="l1 = the BASELINE metric's loss; l1+dssim = 0.8 L1 + 0.2 (1 - SSIM), the reference's full image loss")
+    ap.add_argument("--prepass", action="store_true",
+                    help="the reference's avatar call pattern: covariance from scaling + rotation_precomp (3x3) and colours "
+                         "from SHs in the canonical frame computed BEFORE the rasterizer (fused N3 ops), passed as "
+                         "cov3D_precomp / colors_precomp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -103,11 +107,29 @@ def main():
     cams = [orbit_camera(f, W, H, device=dev) for f in frames]
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     bg = torch.zeros(3, device=dev)
-    pipe = Pipe(compute_cov3D_python=False)
+    pipe = Pipe(compute_cov3D_python=args.prepass, convert_SHs_python=args.prepass)
+    if args.prepass:
+        # what models/deformer/rigid.py:222-231 attaches: a (detached) forward bone transform per Gaussian and the
+        # rotation matrix composed with it
+        gq = torch.Generator().manual_seed(2)
+        bq = torch.nn.functional.normalize(torch.randn(N, 4, generator=gq), dim=1).to(dev)
+        w, x, y, z = bq.unbind(1)
+        bone = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                            1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                            1 - 2 * (x * x + y * y)], 1).view(N, 3, 3)
+        cloud.fwd_transform = bone
+        q = torch.nn.functional.normalize(cloud.rotations.detach(), dim=1)
+        w, x, y, z = q.unbind(1)
+        Rg = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                          1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                          1 - 2 * (x * x + y * y)], 1).view(N, 3, 3)
+        cloud.rotation_precomp = Rg.contiguous().requires_grad_(do_bwd)
 
     def step(i):
         for f in GaussianCloud.FIELDS:
             getattr(cloud, f).grad = None
+        if args.prepass:
+            cloud.rotation_precomp.grad = None
         if do_bwd:
             pkg = render(cams[i], cloud, pipe, bg)
             loss = l1_loss(pkg.render, gt)
@@ -185,7 +207,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
-                "L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss"),
+                ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss") +
+                (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "")),
                 "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
                 "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
                 "broadcast_s": round(t_bcast, 6)},

@@ -33,7 +33,7 @@ def oracle_scene(cloud, cam, bg=(0.0, 0.0, 0.0), color_mode="sh", cov_mode="scal
         kw["scales"] = cloud.scales.numpy()
         kw["rotations"] = cloud.rotations.numpy()
     else:
-        kw["cov3D_precomp"] = cloud.covariance6(scale_modifier).numpy()
+        kw["cov3D_precomp"] = covariance6_cpu(cloud, scale_modifier).numpy()
     return gs_oracle.Scene(cam.image_width, cam.image_height, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                            np.asarray(bg, np.float32), cam.world_view_transform.numpy(),
                            cam.full_proj_transform.numpy(), cam.camera_center.numpy(), cloud.xyz.numpy(),
@@ -133,3 +133,17 @@ def sh2rgb_float64(features, xyz, campos, deg, fwd_rot, noise, g):
     (col * torch.from_numpy(np.asarray(g, np.float32)).double()).sum().backward()
     gp = p.grad.numpy() if p.grad is not None else np.zeros(p.shape)  # degree 0 does not depend on the direction
     return col.detach().numpy(), f.grad.numpy(), gp
+
+
+def covariance6_cpu(cloud, scale_modifier=1.0):
+    """Test input builder (any valid covariance will do): strip_symmetric((R S)(R S)^T) of a CPU cloud in plain
+    torch.  The product's GaussianCloud.covariance6 is the fused HIP op (GPU only)."""
+    import torch
+    q = cloud.rotations / cloud.rotations.norm(dim=1, keepdim=True)
+    r, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+    L = R * (scale_modifier * cloud.scales).unsqueeze(1)
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).contiguous()
