@@ -422,6 +422,13 @@ int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const f
                                 (hipStream_t)stream);
 }
 
+int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, int32_t K, float* dists, int64_t* idx,
+               void* workspace, size_t workspace_bytes, void* stream) {
+    if (Nq < 0 || Nr <= 0 || K < 1 || K > 8 || (Nq > 0 && (!queries || !dists || !idx)) || !ref || !workspace) return GS_E_BAD_ARG;
+    if (Nq == 0) return GS_OK;
+    return launch_knn_points(Nq, queries, Nr, ref, K, dists, (long long*)idx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {
     if (!geom || !out || P < 0) return GS_E_BAD_ARG;
     const GeomLayout L = geom_layout(P);

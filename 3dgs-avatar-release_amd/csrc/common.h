@@ -163,6 +163,10 @@ int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint3
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
                   hipStream_t s);
 
+// K nearest reference points of every query (knn.hip, row N4); workspace = knn_ws_bytes(Nr)
+int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, int K, float* out_d, long long* out_i,
+                      void* ws, size_t ws_bytes, hipStream_t s);
+
 // pre-rasterizer per-Gaussian chains (prepass.hip, row N3)
 int launch_build_cov(int N, const float* scales, float mod, const float* rot, int is_matrix, float* cov6, hipStream_t s);
 int launch_build_cov_bwd(int N, const float* scales, float mod, const float* rot, int is_matrix, const float* dL_dcov6,

@@ -12,6 +12,7 @@
 #include <float.h>
 
 #define KNN_BOX 256
+#define KNN_WAVE 64  // the search kernels run one wave per workgroup: their barriers and votes are wave-level
 
 struct KnnLayout {
     size_t key0, key1, val0, val1, hist, pts, boxes, minmax, total;
@@ -151,35 +152,188 @@ __device__ __forceinline__ float dist2(const float4 a, const float4 b) {
     return dx * dx + dy * dy + dz * dz;
 }
 
-__global__ __launch_bounds__(256) void knn_search_kernel(int P, int nbox, const float4* __restrict__ sp,
+// The points of the box being scanned are staged in LDS by the whole workgroup: its 256 queries are consecutive in Morton order, so they want nearly the same boxes, and a
+// per-thread walk over global memory pays a full memory latency per point (one dependent load per iteration).
+// A box is loaded when ANY query of the group wants it; each query still scans only the boxes it wants itself,
+// so the results are those of the per-thread walk.
+
+__global__ __launch_bounds__(KNN_WAVE) void knn_search_kernel(int P, int nbox, const float4* __restrict__ sp,
                                                          const float* __restrict__ boxes, float* __restrict__ out) {
+    __shared__ float4 tile[KNN_BOX];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const float4 p = sp[r];
+    const bool active = r < P;
+    const float4 p = active ? sp[r] : make_float4(0.f, 0.f, 0.f, 0.f);
     float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
     // seed the rejection radius from the Morton neighbours
-    for (int i = max(0, r - 3); i <= min(P - 1, r + 3); i++) {
-        if (i == r) continue;
-        kbest3(dist2(p, sp[i]), best);
-    }
-    const float reject = best[2];
-    best[0] = best[1] = best[2] = FLT_MAX;
-    for (int b = 0; b < nbox; b++) {
-        const float4 lo = *reinterpret_cast<const float4*>(boxes + b * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(boxes + b * 8 + 4);
-        // gap per axis, written as (point - nearest box point) so it rounds like dist2()
-        const float gx = (p.x < lo.x) ? (p.x - lo.x) : ((p.x > hi.x) ? (p.x - hi.x) : 0.f);
-        const float gy = (p.y < lo.y) ? (p.y - lo.y) : ((p.y > hi.y) ? (p.y - hi.y) : 0.f);
-        const float gz = (p.z < lo.z) ? (p.z - lo.z) : ((p.z > hi.z) ? (p.z - hi.z) : 0.f);
-        const float dbox = gx * gx + gy * gy + gz * gz;
-        if (dbox > reject || dbox > best[2]) continue;
-        const int e = min(P, (b + 1) * KNN_BOX);
-        for (int i = b * KNN_BOX; i < e; i++) {
+    if (active)
+        for (int i = max(0, r - 3); i <= min(P - 1, r + 3); i++) {
             if (i == r) continue;
             kbest3(dist2(p, sp[i]), best);
         }
+    const float reject = best[2];
+    best[0] = best[1] = best[2] = FLT_MAX;
+    // boxes are visited outwards from the group's own box (its 256 queries ARE box blockIdx.x), so the K-th best
+    // distance is tight before the far boxes are tested -- most of them then fail the AABB test
+    const int own = (int)(blockIdx.x * KNN_WAVE) / KNN_BOX;  // a wave's 64 queries lie in one box
+    for (int d = 0; own + d < nbox || own - d >= 0; d++) {
+        for (int side = 0; side < 2; side++) {
+            const int b = side == 0 ? own + d : own - d;
+            if ((d == 0 && side == 1) || b < 0 || b >= nbox) continue;  // uniform
+            const float4 lo = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8);  // wave-uniform address
+            const float4 hi = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8 + 4);
+            // gap per axis, written as (point - nearest box point) so it rounds like dist2()
+            const float gx = (p.x < lo.x) ? (p.x - lo.x) : ((p.x > hi.x) ? (p.x - hi.x) : 0.f);
+            const float gy = (p.y < lo.y) ? (p.y - lo.y) : ((p.y > hi.y) ? (p.y - hi.y) : 0.f);
+            const float gz = (p.z < lo.z) ? (p.z - lo.z) : ((p.z > hi.z) ? (p.z - hi.z) : 0.f);
+            const float dbox = gx * gx + gy * gy + gz * gz;
+            const bool want = active && !(dbox > reject || dbox > best[2]);
+            if (!__any(want)) continue;  // wave-uniform
+            __syncthreads();  // (one wave: orders the previous scan before this refill)
+            const int base = b * KNN_BOX, cnt = min(P - base, KNN_BOX);
+            for (int e = threadIdx.x; e < cnt; e += KNN_WAVE) tile[e] = sp[base + e];
+            __syncthreads();
+            if (want)
+                for (int i = 0; i < cnt; i++) {
+                    const float dd = dist2(p, tile[i]);
+                    if (dd < best[2] && base + i != r) kbest3(dd, best);  // (equal to the third best changes nothing)
+                }
+        }
     }
-    out[__float_as_uint(p.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+    if (active) out[__float_as_uint(p.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+// ---- general K nearest neighbours (pytorch3d.ops.knn_points as the reference calls it,
+// utils/loss_utils.py:76-79,92-96 -- K = 5 / 6 self-KNN of the canonical Gaussians every step -- and
+// models/deformer/rigid.py:43 -- nearest SMPL vertex, K = 1).  Same machinery as distCUDA2: the REFERENCE set is
+// Morton-ordered and boxed; every query scans the boxes, skipping those whose AABB is farther than its
+// current K-th best (exact in fp32, see the header).  Results: squared distances ascending, ties broken by the
+// smaller reference index; the query point itself is NOT excluded (a self-KNN returns itself first, as
+// pytorch3d does).
+#define KNN_MAXK 8
+
+// (K is a template parameter everywhere: a run-time K would index the two lists dynamically, which puts them in
+// scratch memory -- measured 30x slower)
+template <int K>
+__device__ __forceinline__ void kbest_insert(float d, uint32_t id, float* bd, uint32_t* bi) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (bd[k] > d || (bd[k] == d && bi[k] > id)) {
+            const float td = bd[k];
+            const uint32_t ti = bi[k];
+            bd[k] = d; bi[k] = id;
+            d = td; id = ti;
+        }
+    }
+}
+
+// sorted_queries: the queries ARE the Morton-ordered reference points (self-KNN; query r = sp[r], answers go to
+// row sp[r].w); otherwise queries[q] is read in the given order.
+template <int K>
+__global__ __launch_bounds__(KNN_WAVE) void knn_points_kernel(int Nq, const float* __restrict__ queries, int sorted_queries,
+                                                         int Nr, int nbox, const float4* __restrict__ sp,
+                                                         const float* __restrict__ boxes,
+                                                         float* __restrict__ out_d, long long* __restrict__ out_i) {
+    __shared__ float4 tile[KNN_BOX];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = r < Nq;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t row = 0;
+    if (active) {
+        if (sorted_queries) {
+            p = sp[r];
+            row = __float_as_uint(p.w);
+        } else {
+            p = make_float4(queries[3 * (size_t)r], queries[3 * (size_t)r + 1], queries[3 * (size_t)r + 2], 0.f);
+            row = (size_t)r;
+        }
+    }
+    float bd[K];
+    uint32_t bi[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = 0xFFFFFFFFu; }
+    float reject = FLT_MAX;
+    if (sorted_queries && active) {
+        // seed the rejection radius from the Morton neighbours (they are re-found in the scan below)
+        for (int i = max(0, r - K); i <= min(Nr - 1, r + K); i++) kbest_insert<K>(dist2(p, sp[i]), __float_as_uint(sp[i].w), bd, bi);
+        reject = bd[K - 1];
+#pragma unroll
+        for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = 0xFFFFFFFFu; }
+    }
+    // self-KNN: the group's 256 queries are box blockIdx.x; visit the boxes outwards from it so the K-th best
+    // distance is tight before the far boxes are tested.  Foreign queries have no such order: from box 0 upwards.
+    const int own = sorted_queries ? (int)(blockIdx.x * KNN_WAVE) / KNN_BOX : 0;  // wave-uniform
+    for (int d = 0; own + d < nbox || own - d >= 0; d++) {
+        for (int side = 0; side < 2; side++) {
+            const int b = side == 0 ? own + d : own - d;
+            if ((d == 0 && side == 1) || b < 0 || b >= nbox) continue;  // uniform
+            const float4 lo = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8);  // wave-uniform address
+            const float4 hi = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8 + 4);
+            const float gx = (p.x < lo.x) ? (p.x - lo.x) : ((p.x > hi.x) ? (p.x - hi.x) : 0.f);
+            const float gy = (p.y < lo.y) ? (p.y - lo.y) : ((p.y > hi.y) ? (p.y - hi.y) : 0.f);
+            const float gz = (p.z < lo.z) ? (p.z - lo.z) : ((p.z > hi.z) ? (p.z - hi.z) : 0.f);
+            const float dbox = gx * gx + gy * gy + gz * gz;
+            const bool want = active && !(dbox > reject || dbox > bd[K - 1]);
+            if (!__any(want)) continue;  // wave-uniform
+            __syncthreads();  // (one wave: orders the previous scan before this refill)
+            const int base = b * KNN_BOX, cnt = min(Nr - base, KNN_BOX);
+            for (int e = threadIdx.x; e < cnt; e += KNN_WAVE) tile[e] = sp[base + e];
+            __syncthreads();
+            if (want)
+                for (int i = 0; i < cnt; i++) {
+                    const float4 o = tile[i];
+                    const float dd = dist2(p, o);
+                    const uint32_t id = __float_as_uint(o.w);
+                    // most points are no better than the current K-th best: one compare instead of the K-deep
+                    // insertion chain (which a wave only enters when one of its lanes has a candidate)
+                    if (dd < bd[K - 1] || (dd == bd[K - 1] && id < bi[K - 1])) kbest_insert<K>(dd, id, bd, bi);
+                }
+        }
+    }
+    if (active)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            out_d[row * K + k] = bd[k];
+            out_i[row * K + k] = (bi[k] == 0xFFFFFFFFu) ? -1ll : (long long)bi[k];  // fewer than K reference points: -1
+        }
+}
+
+int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, int K, float* out_d, long long* out_i,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
+    const KnnLayout L = knn_layout(Nr);
+    if (ws_bytes < L.total) return GS_E_WORKSPACE;
+    char* w = (char*)ws;
+    uint32_t* k0 = (uint32_t*)(w + L.key0);
+    uint32_t* k1 = (uint32_t*)(w + L.key1);
+    uint32_t* v0 = (uint32_t*)(w + L.val0);
+    uint32_t* v1 = (uint32_t*)(w + L.val1);
+    uint32_t* hist = (uint32_t*)(w + L.hist);
+    float4* sp = (float4*)(w + L.pts);
+    float* boxes = (float*)(w + L.boxes);
+    uint32_t* mm = (uint32_t*)(w + L.minmax);
+    const int nb = (Nr + 255) / 256;
+    StageScope st("knn_points", s);
+    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(64), 0, s, mm);
+    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, Nr, ref, mm);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, mm, k0, v0);
+    GS_LAUNCH_CHECK("knn.morton", 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, Nr, 30, false, 0, s);
+    if (rc != GS_OK) return rc;
+    const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
+    hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, order, sp);
+    hipLaunchKernelGGL(knn_box_kernel, dim3(L.nbox), dim3(KNN_BOX), 0, s, Nr, sp, boxes);
+    const int self = (queries == ref && Nq == Nr) ? 1 : 0;
+#define KNN_LAUNCH(KK)                                                                                                   \
+    case KK:                                                                                                             \
+        hipLaunchKernelGGL(knn_points_kernel<KK>, dim3((Nq + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, Nq, queries, self, Nr, L.nbox, sp, \
+                           boxes, out_d, out_i);                                                                         \
+        break;
+    switch (K) {
+        KNN_LAUNCH(1) KNN_LAUNCH(2) KNN_LAUNCH(3) KNN_LAUNCH(4) KNN_LAUNCH(5) KNN_LAUNCH(6) KNN_LAUNCH(7) KNN_LAUNCH(8)
+        default: return GS_E_BAD_ARG;
+    }
+#undef KNN_LAUNCH
+    GS_LAUNCH_CHECK("knn.points", 0, s);
+    return GS_OK;
 }
 
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -204,7 +358,7 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp);
     hipLaunchKernelGGL(knn_box_kernel, dim3(L.nbox), dim3(KNN_BOX), 0, s, P, sp, boxes);
-    hipLaunchKernelGGL(knn_search_kernel, dim3(nb), dim3(256), 0, s, P, L.nbox, sp, boxes, out);
+    hipLaunchKernelGGL(knn_search_kernel, dim3((P + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, P, L.nbox, sp, boxes, out);
     GS_LAUNCH_CHECK("knn.search", 0, s);
     return GS_OK;
 }

@@ -182,6 +182,15 @@ int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const f
                      const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dssim, float* dL_dimg1,
                      void* stream);
 
+/* ---- K nearest neighbours: pytorch3d.ops.knn_points as the reference calls it
+ * (utils/loss_utils.py:76-79,92-96: K = 5 / 6 self-KNN of the canonical Gaussians for the AIAP loss;
+ * models/deformer/rigid.py:43: nearest SMPL vertex, K = 1).  For every query the K (<= 8) nearest points of
+ * `ref`: squared distances ascending and their indices into `ref` (ties: smaller index first; -1 / FLT_MAX when
+ * ref has fewer than K points).  A query that is itself in `ref` is returned as its own first neighbour, as
+ * pytorch3d does.  Exact (no approximation).  Workspace: knn_workspace_bytes(Nr). ---- */
+int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, int32_t K, float* dists, int64_t* idx,
+               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
  *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
  *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))

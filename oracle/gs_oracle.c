@@ -862,6 +862,31 @@ int or_sh2rgb(int N, int deg, int M, const float* shs, const float* xyz, const f
     return 0;
 }
 
+/* N4: K nearest reference points of every query, brute force (pytorch3d.ops.knn_points semantics as the
+ * reference uses them: squared distances ascending; a query contained in ref finds itself first).  Distance
+ * dx*dx + dy*dy + dz*dz in fp32; ties broken by the smaller reference index. */
+int or_knn_points(int Nq, const float* q, int Nr, const float* ref, int K, float* dists, long long* idx) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < Nq; i++) {
+        float bd[8];
+        long long bi[8];
+        for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = -1; }
+        const float* p = q + 3 * (size_t)i;
+        for (int j = 0; j < Nr; j++) {
+            const float dx = p[0] - ref[3 * (size_t)j], dy = p[1] - ref[3 * (size_t)j + 1], dz = p[2] - ref[3 * (size_t)j + 2];
+            float d = dx * dx + dy * dy + dz * dz;
+            long long id = j;
+            for (int k = 0; k < K; k++)
+                if (bd[k] > d || (bd[k] == d && (bi[k] > id || bi[k] < 0))) {
+                    const float td = bd[k]; const long long ti = bi[k];
+                    bd[k] = d; bi[k] = id; d = td; id = ti;
+                }
+        }
+        for (int k = 0; k < K; k++) { dists[(size_t)i * K + k] = bd[k]; idx[(size_t)i * K + k] = bi[k]; }
+    }
+    return 0;
+}
+
 void or_set_num_threads(int n) {
 #ifdef _OPENMP
     extern void omp_set_num_threads(int);

@@ -270,6 +270,15 @@ def sh2rgb(features, xyz, campos, deg, fwd_rot=None, noise=None, dL_dcolors=None
     return col, cl, dsh, dp
 
 
+def knn_points(queries, ref, K):
+    """N4 restatement: (squared distances (Nq,K) ascending, indices (Nq,K) int64), brute force."""
+    q, r = _f32(queries).reshape(-1, 3), _f32(ref).reshape(-1, 3)
+    d = np.zeros((q.shape[0], K), np.float32)
+    ix = np.zeros((q.shape[0], K), np.int64)
+    lib().or_knn_points(c_int(q.shape[0]), _ptr(q), c_int(r.shape[0]), _ptr(r), c_int(K), _ptr(d), _ptr(ix))
+    return d, ix
+
+
 def set_num_threads(n):
     lib().or_set_num_threads(c_int(int(n)))
 

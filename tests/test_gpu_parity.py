@@ -545,3 +545,31 @@ def test_render_harness_prepass_path_matches_in_kernel_path(oracle):
                      c.scales.grad.cpu().numpy())
     for a, b, nm in zip(out["kernel"], out["prepass"], ["image", "d/dshs", "d/dxyz", "d/dscales"]):
         _bulk_close(b, a, tol=2e-5, frac=1e-3, name=nm)
+
+
+@pytest.mark.gpu
+def test_knn_points_exact_vs_oracle(oracle):
+    """N4: gsplat_mi355.knn.knn_points (pytorch3d.ops.knn_points call shape) == brute force, bit-exact distances and
+    identical indices: self-KNN K = 6 (utils/loss_utils.py:92-96), K = 5 (:76-79), query vs a small vertex set
+    K = 1 (models/deformer/rigid.py:43), duplicated points, fewer reference points than K."""
+    from gsplat_mi355.knn import knn_points
+    rng = np.random.default_rng(6)
+    pts = np.concatenate([rng.normal(size=(20000, 3)), 0.01 * rng.normal(size=(3000, 3)) + 2.0]).astype(np.float32)
+    pts[100:110] = pts[0:10]  # duplicates
+    x = torch.from_numpy(pts).cuda()
+    for K in (6, 5, 1):
+        want_d, want_i = oracle.knn_points(pts, pts, K)
+        got = knn_points(x[None], x[None], K=K, return_sorted=True)
+        assert got.idx.shape == (1, len(pts), K) and got.idx.dtype == torch.int64
+        assert np.array_equal(got.dists[0].cpu().numpy(), want_d)
+        assert np.array_equal(got.idx[0].cpu().numpy(), want_i)
+    verts = rng.normal(size=(6890, 3)).astype(np.float32)
+    want_d, want_i = oracle.knn_points(pts, verts, 1)
+    got = knn_points(x.unsqueeze(0), torch.from_numpy(verts).cuda().unsqueeze(0))
+    assert np.array_equal(got.idx[0, :, 0].cpu().numpy(), want_i[:, 0])
+    assert np.array_equal(got.dists[0].cpu().numpy(), want_d)
+    few = torch.from_numpy(verts[:3]).cuda()
+    got = knn_points(x[:10], few, K=5)
+    assert np.all(got.idx[:, 3:].cpu().numpy() == -1) and np.all(got.idx[:, :3].cpu().numpy() >= 0)
+    with pytest.raises(RuntimeError):
+        knn_points(torch.from_numpy(pts), torch.from_numpy(pts), K=3)

@@ -363,3 +363,22 @@ def test_sh2rgb_oracle_vs_reference_golden_and_float64_autograd(oracle):
         assert np.abs(col - col64).max() <= 1e-6
         assert np.abs(dsh - dsh64).max() <= 1e-6 * max(np.abs(dsh64).max(), 1e-30)
         assert np.abs(dp - dp64).max() <= 1e-6 * max(np.abs(dp64).max(), 1e-30)
+
+
+def test_knn_points_oracle_vs_scipy_kdtree(oracle):
+    """N4 oracle: K nearest (self included) against scipy's cKDTree; ties by index on duplicated points."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(700, 3)).astype(np.float32)
+    d, ix = oracle.knn_points(pts, pts, 6)
+    dd, ii = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=6)
+    assert np.array_equal(ix, ii)
+    assert np.allclose(d, dd ** 2, rtol=1e-5, atol=1e-7)
+    assert np.all(ix[:, 0] == np.arange(700)) and np.all(d[:, 0] == 0)
+    dup = np.concatenate([pts[:5], pts[:5], pts[5:50]])
+    d, ix = oracle.knn_points(dup, dup, 2)
+    assert np.array_equal(ix[:5], np.stack([np.arange(5), np.arange(5) + 5], 1))  # equal distance 0: smaller index first
+    q = rng.normal(size=(40, 3)).astype(np.float32)
+    d1, i1 = oracle.knn_points(q, pts, 1)
+    _, j1 = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=1)
+    assert np.array_equal(i1[:, 0], j1)
