@@ -422,6 +422,23 @@ int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const f
                                 (hipStream_t)stream);
 }
 
+int gs_densify_stats(int32_t N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
+                     float* xyz_gradient_accum, float* denom, void* stream) {
+    if (N < 0 || (N > 0 && (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom))) return GS_E_BAD_ARG;
+    if (N == 0) return GS_OK;
+    return launch_densify_stats(N, radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, (hipStream_t)stream);
+}
+int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, double beta2, double eps, int64_t step,
+                 void* stream) {
+    if (n_tensors < 0 || n_tensors > GS_ADAM_MAX_TENSORS || (n_tensors > 0 && !tensors) || step < 1) return GS_E_BAD_ARG;
+    for (int k = 0; k < n_tensors; k++) {
+        const GsAdamTensor& t = tensors[k];
+        if (t.n < 0 || (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq))) return GS_E_BAD_ARG;
+    }
+    if (n_tensors == 0) return GS_OK;
+    return launch_adam(n_tensors, tensors, beta1, beta2, eps, step, (hipStream_t)stream);
+}
+
 int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, int32_t K, float* dists, int64_t* idx,
                void* workspace, size_t workspace_bytes, void* stream) {
     if (Nq < 0 || Nr <= 0 || K < 1 || K > 8 || (Nq > 0 && (!queries || !dists || !idx)) || !ref || !workspace) return GS_E_BAD_ARG;

@@ -163,6 +163,11 @@ int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint3
 int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
                   hipStream_t s);
 
+// training-step bookkeeping (optim.hip, row N4)
+int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
+                         float* xyz_gradient_accum, float* denom, hipStream_t s);
+int launch_adam(int n, const GsAdamTensor* tensors, double beta1, double beta2, double eps, int64_t step, hipStream_t s);
+
 // K nearest reference points of every query (knn.hip, row N4); workspace = knn_ws_bytes(Nr)
 int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, int K, float* out_d, long long* out_i,
                       void* ws, size_t ws_bytes, hipStream_t s);

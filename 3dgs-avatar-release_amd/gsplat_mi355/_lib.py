@@ -3,7 +3,7 @@ library is missing or a call fails, this raises."""
 import ctypes
 import os
 import threading
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsplat_mi355.so")
@@ -30,9 +30,16 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
-           "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points"]
+           "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
+GS_ADAM_MAX_TENSORS = 16
+
+
+class GsAdamTensor(ctypes.Structure):  # include/gsplat_mi355.h: GsAdamTensor
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("n", c_int64), ("lr", c_float)]
+
 
 _lock = threading.Lock()
 _lib = None
@@ -83,6 +90,8 @@ def load():
         L.gs_sh2rgb_backward.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]
         L.knn_points.argtypes = [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.gs_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.gs_adam_step.argtypes = [c_int32, POINTER(GsAdamTensor), c_double, c_double, c_double, c_int64, c_void_p]
         L.gs_geom_field.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]

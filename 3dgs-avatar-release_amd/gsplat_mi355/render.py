@@ -191,10 +191,8 @@ class DensifyStats(object):
         self.denom = torch.zeros(n, 1, device=device)
 
     def update(self, pkg):
-        vf, radii = pkg.visibility_filter, pkg.radii
-        self.max_radii2D[vf] = torch.max(self.max_radii2D[vf], radii[vf].float())
-        self.xyz_gradient_accum[vf] += torch.norm(pkg.viewspace_points.grad[vf, :2], dim=-1, keepdim=True)
-        self.denom[vf] += 1
+        from .optim import densify_stats  # one fused kernel, no boolean-mask indexing (row N4)
+        densify_stats(pkg.radii, pkg.viewspace_points.grad, self.max_radii2D, self.xyz_gradient_accum, self.denom)
 
 
 def train_step(data, pc, pipe, bg_color, gt_image, gt_mask=None, lambda_mask=0.0, stats=None):

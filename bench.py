@@ -65,6 +65,9 @@ def main():
                     help="the reference's avatar call pattern: covariance from scaling + rotation_precomp (3x3) and colours "
                          "from SHs in the canonical frame computed BEFORE the rasterizer (fused N3 ops), passed as "
                          "cov3D_precomp / colors_precomp")
+    ap.add_argument("--train-step", action="store_true",
+                    help="also run what follows the backward in the reference's step: densification statistics and the Adam "
+                         "update of all parameters (fused N4 ops)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -125,6 +128,15 @@ def main():
                           1 - 2 * (x * x + y * y)], 1).view(N, 3, 3)
         cloud.rotation_precomp = Rg.contiguous().requires_grad_(do_bwd)
 
+    opt = stats = None
+    if args.train_step and do_bwd:
+        from gsplat_mi355.optim import FusedAdam
+        from gsplat_mi355.render import DensifyStats
+        lrs = dict(xyz=1.6e-4, scales=5e-3, rotations=1e-3, opacity=5e-2, shs=2.5e-3)  # configs/opt defaults
+        opt = FusedAdam([{"params": [getattr(cloud, f)], "lr": lrs.get(f, 1e-3), "name": f} for f in GaussianCloud.FIELDS],
+                        lr=0.0, eps=1e-15)
+        stats = DensifyStats(N, dev)
+
     def step(i):
         for f in GaussianCloud.FIELDS:
             getattr(cloud, f).grad = None
@@ -136,6 +148,10 @@ def main():
             if args.loss == "l1+dssim":  # train.py:120-124 with lambda_l1 = 0.8, lambda_dssim = 0.2
                 loss = 0.8 * loss + 0.2 * (1.0 - ssim(pkg.render, gt))
             loss.backward()
+            if opt is not None:
+                with torch.no_grad():
+                    stats.update(pkg)
+                opt.step()
         else:
             with torch.no_grad():
                 pkg = render(cams[i], cloud, pipe, bg)
@@ -208,7 +224,8 @@ def main():
             "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
                 ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss") +
-                (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "")),
+                (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "") +
+                (", + densification statistics + Adam step" if args.train_step else "")),
                 "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
                 "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
                 "broadcast_s": round(t_bcast, 6)},

@@ -191,6 +191,27 @@ int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const f
 int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, int32_t K, float* dists, int64_t* idx,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training-step bookkeeping after the backward pass.
+ * gs_densify_stats: train.py:219-220 + scene/gaussian_model.py:464-466, for every Gaussian with radii > 0:
+ *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |viewspace_grad[:2]|; denom += 1
+ *   (viewspace_grad is the (N,3) gradient of the screen-space points the rasterizer returns for means2D).
+ * gs_adam_step: torch.optim.Adam as scene/gaussian_model.py:201-216 sets it up (one learning rate per tensor,
+ *   shared betas / eps, no weight decay, no amsgrad), step number `step` >= 1, all tensors in ONE launch;
+ *   exp_avg / exp_avg_sq are the optimizer's state tensors and are updated in place, as is param. ---- */
+#define GS_ADAM_MAX_TENSORS 16
+typedef struct GsAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;   /* elements */
+    float lr;
+} GsAdamTensor;
+int gs_densify_stats(int32_t N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
+                     float* xyz_gradient_accum, float* denom, void* stream);
+int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, double beta2, double eps, int64_t step,
+                 void* stream);
+
 /* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
  *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
  *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))

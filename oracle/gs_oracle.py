@@ -279,6 +279,28 @@ def knn_points(queries, ref, K):
     return d, ix
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """N4 restatement of one torch.optim.Adam step (no weight decay / amsgrad) in float64 numpy; returns the new
+    (param, exp_avg, exp_avg_sq)."""
+    p, g, m, v = (np.asarray(a, np.float64) for a in (param, grad, exp_avg, exp_avg_sq))
+    m = m + (g - m) * (1.0 - beta1)
+    v = v * beta2 + (1.0 - beta2) * g * g
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    p = p - (lr / bc1) * (m / (np.sqrt(v) / np.sqrt(bc2) + eps))
+    return p, m, v
+
+
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+    """N4 restatement of train.py:219-220 + scene/gaussian_model.py:464-466; returns the three updated arrays."""
+    vis = np.asarray(radii) > 0
+    mr, acc, dn = (np.array(a, np.float32).reshape(-1) for a in (max_radii2D, xyz_gradient_accum, denom))
+    g = np.asarray(viewspace_grad, np.float32)
+    mr[vis] = np.maximum(mr[vis], np.asarray(radii)[vis].astype(np.float32))
+    acc[vis] += np.sqrt(g[vis, 0] * g[vis, 0] + g[vis, 1] * g[vis, 1])
+    dn[vis] += 1
+    return mr, acc, dn
+
+
 def set_num_threads(n):
     lib().or_set_num_threads(c_int(int(n)))
 

@@ -573,3 +573,49 @@ def test_knn_points_exact_vs_oracle(oracle):
     assert np.all(got.idx[:, 3:].cpu().numpy() == -1) and np.all(got.idx[:, :3].cpu().numpy() >= 0)
     with pytest.raises(RuntimeError):
         knn_points(torch.from_numpy(pts), torch.from_numpy(pts), K=3)
+
+
+@pytest.mark.gpu
+def test_fused_adam_and_densify_stats_match_oracle_and_torch(oracle):
+    """N4: gsplat_mi355.optim.FusedAdam follows torch.optim.Adam(l, lr=0.0, eps=1e-15) with the reference's six
+    parameter groups (scene/gaussian_model.py:201-216) step for step (fp32: 1e-6 of the tensor's scale), keeps
+    torch's state layout, and densify_stats reproduces train.py:219-220 + gaussian_model.py:464-466 exactly."""
+    from gsplat_mi355.optim import FusedAdam, densify_stats
+    rng = np.random.default_rng(12)
+    n = 5000
+    shapes = [(n, 3), (n, 1, 3), (n, 15, 3), (n, 1), (n, 3), (n, 4)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3]
+    init = [rng.normal(size=s).astype(np.float32) for s in shapes]
+    dev = torch.device("cuda:0")
+    mine = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in init]
+    ref = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in init]
+    o_mine = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(mine, lrs))], lr=0.0, eps=1e-15)
+    o_ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref, lrs)], lr=0.0, eps=1e-15)
+    orc = [(a.astype(np.float64), np.zeros(a.shape), np.zeros(a.shape)) for a in init]
+    for step in range(1, 5):
+        grads = [(rng.normal(size=s) * 10.0 ** rng.integers(-4, 1)).astype(np.float32) for s in shapes]
+        grads[0][::2] = 0.0
+        for pm, pr, g in zip(mine, ref, grads):
+            pm.grad = torch.from_numpy(g).to(dev)
+            pr.grad = torch.from_numpy(g).to(dev)
+        o_mine.step()
+        o_ref.step()
+        orc = [oracle.adam_step(p, g, m, v, lr, 0.9, 0.999, 1e-15, step) for (p, m, v), g, lr in zip(orc, grads, lrs)]
+        for pm, pr, (q, m, v) in zip(mine, ref, orc):
+            got = pm.detach().cpu().numpy().astype(np.float64)
+            scale = np.abs(q).max()
+            assert np.abs(got - q).max() <= 2e-6 * scale
+            assert np.abs(got - pr.detach().cpu().numpy()).max() <= 2e-6 * scale
+            st = o_mine.state[pm]
+            assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == step
+            assert np.abs(st["exp_avg"].cpu().numpy() - m).max() <= 2e-6 * max(np.abs(m).max(), 1e-30)
+            assert np.abs(st["exp_avg_sq"].cpu().numpy() - v).max() <= 2e-6 * max(np.abs(v).max(), 1e-30)
+    radii = rng.integers(-1, 40, size=n).astype(np.int32)
+    radii[radii < 0] = 0
+    vg = rng.normal(size=(n, 3)).astype(np.float32)
+    mr, acc, dn = (rng.random(n).astype(np.float32) * 20 for _ in range(3))
+    want = oracle.densify_stats(radii, vg, mr, acc, dn)
+    t = [torch.from_numpy(a).to(dev) for a in (mr, acc.reshape(n, 1), dn.reshape(n, 1))]
+    densify_stats(torch.from_numpy(radii).to(dev), torch.from_numpy(vg).to(dev), *t)
+    for got, w in zip(t, want):
+        assert np.array_equal(got.cpu().numpy().reshape(-1), w)

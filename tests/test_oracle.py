@@ -382,3 +382,25 @@ def test_knn_points_oracle_vs_scipy_kdtree(oracle):
     d1, i1 = oracle.knn_points(q, pts, 1)
     _, j1 = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=1)
     assert np.array_equal(i1[:, 0], j1)
+
+
+def test_adam_oracle_vs_torch_optim_adam(oracle):
+    """N4 oracle: the float64 Adam restatement reproduces torch.optim.Adam(l, lr=0.0, eps=1e-15) as
+    scene/gaussian_model.py:201-216 builds it (per-group learning rates), over several steps, on the CPU."""
+    import torch
+    rng = np.random.default_rng(4)
+    shapes, lrs = [(50, 3), (50, 1, 3), (50, 15, 3), (50, 1)], [1.6e-4, 2.5e-3, 1.25e-4, 5e-2]
+    params = [torch.nn.Parameter(torch.from_numpy(rng.normal(size=s)).double()) for s in shapes]
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(params, lrs)], lr=0.0, eps=1e-15)
+    mine = [(p.detach().numpy().copy(), np.zeros(s), np.zeros(s)) for p, s in zip(params, shapes)]
+    for step in range(1, 6):
+        grads = [rng.normal(size=s) * (step % 2 + 0.1) for s in shapes]
+        grads[0][::3] = 0.0  # culled Gaussians have zero gradients: Adam still moves them with the old moments
+        for p, g in zip(params, grads):
+            p.grad = torch.from_numpy(g)
+        opt.step()
+        mine = [oracle.adam_step(p, g, m, v, lr, 0.9, 0.999, 1e-15, step) for (p, m, v), g, lr in zip(mine, grads, lrs)]
+        for p, (q, m, v) in zip(params, mine):
+            assert np.allclose(p.detach().numpy(), q, rtol=1e-12, atol=1e-15)
+            assert np.allclose(opt.state[p]["exp_avg"].numpy(), m, rtol=1e-12, atol=1e-18)
+            assert np.allclose(opt.state[p]["exp_avg_sq"].numpy(), v, rtol=1e-12, atol=1e-18)
