@@ -619,3 +619,45 @@ def test_fused_adam_and_densify_stats_match_oracle_and_torch(oracle):
     densify_stats(torch.from_numpy(radii).to(dev), torch.from_numpy(vg).to(dev), *t)
     for got, w in zip(t, want):
         assert np.array_equal(got.cpu().numpy().reshape(-1), w)
+
+
+@pytest.mark.gpu
+def test_end_to_end_optimisation_reduces_the_loss():
+    """Everything together, as the reference's training step strings it: render -> 0.8 L1 + 0.2 D-SSIM -> backward ->
+    densification statistics -> Adam (all through the HIP library).  Fitting a perturbed cloud to the image of the
+    unperturbed one must reduce the loss substantially in 40 steps, with finite parameters throughout."""
+    from gsplat_mi355.camera import orbit_camera
+    from gsplat_mi355.optim import FusedAdam
+    from gsplat_mi355.render import DensifyStats, Pipe, l1_loss, render, ssim
+    from gsplat_mi355.scenes import GaussianCloud
+    dev = torch.device("cuda:0")
+    cloud, _ = helpers.cloud_and_camera(4000, 128, 128, sh_degree=1, seed=7)
+    cam = orbit_camera(0, 128, 128, device=dev)
+    bg = torch.zeros(3, device=dev)
+    target_cloud = GaussianCloud(*[getattr(cloud, f).to(dev) for f in GaussianCloud.FIELDS], cloud.sh_degree)
+    with torch.no_grad():
+        gt = render(cam, target_cloud, Pipe(), bg).render.clone()
+    g = torch.Generator().manual_seed(0)
+    fields = {f: getattr(cloud, f).clone() for f in GaussianCloud.FIELDS}
+    fields["shs"] = fields["shs"] + 0.3 * torch.randn(fields["shs"].shape, generator=g)
+    fields["opacity"] = (fields["opacity"] * 0.6).clamp(0.01, 0.99)
+    c = GaussianCloud(*[fields[f].to(dev).requires_grad_(True) for f in GaussianCloud.FIELDS], cloud.sh_degree)
+    lrs = dict(xyz=1e-4, scales=1e-3, rotations=1e-3, opacity=2e-2, shs=2e-2)
+    opt = FusedAdam([{"params": [getattr(c, f)], "lr": lrs[f], "name": f} for f in GaussianCloud.FIELDS], lr=0.0, eps=1e-15)
+    stats = DensifyStats(4000, dev)
+    losses = []
+    for it in range(40):
+        opt.zero_grad(set_to_none=True)
+        pkg = render(cam, c, Pipe(), bg)
+        loss = 0.8 * l1_loss(pkg.render, gt) + 0.2 * (1.0 - ssim(pkg.render, gt))
+        loss.backward()
+        with torch.no_grad():
+            stats.update(pkg)
+            opt.step()
+            c.opacity.clamp_(1e-4, 0.9999)  # the reference keeps opacity inside (0, 1) through its sigmoid activation
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(l) for l in losses)
+    assert losses[-1] < 0.6 * losses[0], losses[::8]
+    for f in GaussianCloud.FIELDS:
+        assert torch.isfinite(getattr(c, f)).all()
+    assert float(stats.denom.max()) == 40.0 and float(stats.max_radii2D.max()) > 0
