@@ -76,31 +76,32 @@ int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float
 // SSIM (utils/loss_utils.py:27-67: 11x11 Gaussian window, sigma 1.5, zero
 // padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements) with its gradient w.r.t. the first image.
 // The reference runs five depthwise conv2d launches plus ~15 elementwise ones and lets autograd replay
-// them backwards.  Here: one forward kernel (16x16 output tile per workgroup, 26x26 halo tiles of both
+// them backwards.  Here: one forward kernel (32x32 output tile per workgroup, 42x42 halo tiles of both
 // images in LDS, the 121-tap window applied as two 11-tap passes, five moments at once) that also
 // emits the three partial-derivative maps the backward needs, and one backward kernel that filters
 // those three maps with the same window and combines them with the images.  Reductions are two-stage
 // and ordered: bitwise reproducible.
 // ---------------------------------------------------------------------------------------------
-#define SS_T 16            // output tile edge
+#define SS_T 32            // output tile edge (32 x 32 outputs per workgroup of 256 threads: four per thread)
+#define SS_NT 256
 #define SS_R 5             // window radius
-#define SS_H (SS_T + 2 * SS_R)  // halo tile edge (26)
+#define SS_H (SS_T + 2 * SS_R)  // halo tile edge (42)
 #define SS_C1 0.0001f
 #define SS_C2 0.0009f
 
 struct SsimWindow { float w[11]; };
 
-__global__ __launch_bounds__(SS_T* SS_T) void ssim_fwd_kernel(int H, int W, const float* __restrict__ img1,
-                                                              const float* __restrict__ img2, SsimWindow win,
-                                                              float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1,
-                                                              float* __restrict__ dm_ds12, float* __restrict__ partial) {
+__global__ __launch_bounds__(SS_NT) void ssim_fwd_kernel(int H, int W, const float* __restrict__ img1,
+                                                         const float* __restrict__ img2, SsimWindow win,
+                                                         float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1,
+                                                         float* __restrict__ dm_ds12, float* __restrict__ partial) {
     __shared__ float t1[SS_H][SS_H + 1], t2[SS_H][SS_H + 1];
     __shared__ float hx[5][SS_H][SS_T + 1];
-    __shared__ float ws[SS_T * SS_T / 64];
-    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
+    __shared__ float ws[SS_NT / 64];
+    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;  // ty in 0..7: rows ty, ty + 8, ty + 16, ty + 24
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < SS_H * SS_H; e += SS_T * SS_T) {
+    for (int e = tid; e < SS_H * SS_H; e += SS_NT) {
         const int r = e / SS_H, c = e - r * SS_H;
         const int y = y0 + r - SS_R, x = x0 + c - SS_R;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(SS_T* SS_T) void ssim_fwd_kernel(int H, int W, cons
         t2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    // horizontal pass: 26 rows x 16 columns, five moments
-    for (int e = tid; e < SS_H * SS_T; e += SS_T * SS_T) {
+    // horizontal pass: 42 rows x 32 columns, five moments
+    for (int e = tid; e < SS_H * SS_T; e += SS_NT) {
         const int r = e / SS_T, c = e - r * SS_T;
         float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
@@ -124,34 +125,39 @@ __global__ __launch_bounds__(SS_T* SS_T) void ssim_fwd_kernel(int H, int W, cons
         hx[0][r][c] = m1; hx[1][r][c] = m2; hx[2][r][c] = e11; hx[3][r][c] = e22; hx[4][r][c] = e12;
     }
     __syncthreads();
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        mu1 += w * hx[0][ty + k][tx];
-        mu2 += w * hx[1][ty + k][tx];
-        e11 += w * hx[2][ty + k][tx];
-        e22 += w * hx[3][ty + k][tx];
-        e12 += w * hx[4][ty + k][tx];
-    }
-    const int x = x0 + tx, y = y0 + ty;
     float val = 0.f;
-    if (x < W && y < H) {
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float A = 2.f * mu12 + SS_C1, B = 2.f * s12 + SS_C2;
-        const float C = mu1_sq + mu2_sq + SS_C1, D = s1 + s2 + SS_C2;
-        const float inv_cd = 1.0f / (C * D);
-        val = A * B * inv_cd;
-        if (dm_dmu1) {
-            // ssim as a function of (mu1, E[x^2], E[xy]) of this window; s1 and s12 depend on mu1 too
-            const float d_s1 = -val / D;              // d ssim / d s1   = -A B / (C D^2)
-            const float d_s12 = 2.f * A * inv_cd;     // d ssim / d s12  =  2 A / (C D)
-            const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * val / C - 2.f * mu1 * d_s1 - mu2 * d_s12;
-            const size_t o = plane + (size_t)y * W + x;
-            dm_dmu1[o] = d_mu1;
-            dm_ds1[o] = d_s1;
-            dm_ds12[o] = d_s12;
+#pragma unroll
+    for (int q = 0; q < SS_T * SS_T / SS_NT; q++) {
+        const int oy = ty + q * (SS_NT / SS_T);
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            mu1 += w * hx[0][oy + k][tx];
+            mu2 += w * hx[1][oy + k][tx];
+            e11 += w * hx[2][oy + k][tx];
+            e22 += w * hx[3][oy + k][tx];
+            e12 += w * hx[4][oy + k][tx];
+        }
+        const int x = x0 + tx, y = y0 + oy;
+        if (x < W && y < H) {
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+            const float A = 2.f * mu12 + SS_C1, B = 2.f * s12 + SS_C2;
+            const float C = mu1_sq + mu2_sq + SS_C1, D = s1 + s2 + SS_C2;
+            const float inv_cd = 1.0f / (C * D);
+            const float v = A * B * inv_cd;
+            val += v;
+            if (dm_dmu1) {
+                // ssim as a function of (mu1, E[x^2], E[xy]) of this window; s1 and s12 depend on mu1 too
+                const float d_s1 = -v / D;              // d ssim / d s1   = -A B / (C D^2)
+                const float d_s12 = 2.f * A * inv_cd;   // d ssim / d s12  =  2 A / (C D)
+                const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * v / C - 2.f * mu1 * d_s1 - mu2 * d_s12;
+                const size_t o = plane + (size_t)y * W + x;
+                dm_dmu1[o] = d_mu1;
+                dm_ds1[o] = d_s1;
+                dm_ds12[o] = d_s12;
+            }
         }
     }
 #pragma unroll
@@ -175,19 +181,19 @@ __global__ __launch_bounds__(256) void ssim_final_kernel(const float* __restrict
 }
 
 // dL/dimg1(p) = g/n * sum_q w(q - p) [ dm_dmu1(q) + 2 img1(p) dm_ds1(q) + img2(p) dm_ds12(q) ]
-__global__ __launch_bounds__(SS_T* SS_T) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
-                                                              const float* __restrict__ img2, SsimWindow win,
-                                                              const float* __restrict__ dm_dmu1,
-                                                              const float* __restrict__ dm_ds1,
-                                                              const float* __restrict__ dm_ds12,
-                                                              const float* __restrict__ dL_dssim, float inv_n,
-                                                              float* __restrict__ dL_dimg1) {
+__global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
+                                                         const float* __restrict__ img2, SsimWindow win,
+                                                         const float* __restrict__ dm_dmu1,
+                                                         const float* __restrict__ dm_ds1,
+                                                         const float* __restrict__ dm_ds12,
+                                                         const float* __restrict__ dL_dssim, float inv_n,
+                                                         float* __restrict__ dL_dimg1) {
     __shared__ float t[3][SS_H][SS_H + 1];
     __shared__ float hx[3][SS_H][SS_T + 1];
     const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < SS_H * SS_H; e += SS_T * SS_T) {
+    for (int e = tid; e < SS_H * SS_H; e += SS_NT) {
         const int r = e / SS_H, c = e - r * SS_H;
         const int y = y0 + r - SS_R, x = x0 + c - SS_R;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(SS_T* SS_T) void ssim_bwd_kernel(int H, int W, cons
         t[2][r][c] = in ? dm_ds12[o] : 0.f;
     }
     __syncthreads();
-    for (int e = tid; e < SS_H * SS_T; e += SS_T * SS_T) {
+    for (int e = tid; e < SS_H * SS_T; e += SS_NT) {
         const int r = e / SS_T, c = e - r * SS_T;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -210,19 +216,23 @@ __global__ __launch_bounds__(SS_T* SS_T) void ssim_bwd_kernel(int H, int W, cons
         hx[0][r][c] = a0; hx[1][r][c] = a1; hx[2][r][c] = a2;
     }
     __syncthreads();
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    const float g = dL_dssim[0] * inv_n;
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        f0 += w * hx[0][ty + k][tx];
-        f1 += w * hx[1][ty + k][tx];
-        f2 += w * hx[2][ty + k][tx];
-    }
-    const int x = x0 + tx, y = y0 + ty;
-    if (x < W && y < H) {
-        const size_t o = plane + (size_t)y * W + x;
-        const float g = dL_dssim[0] * inv_n;
-        dL_dimg1[o] = g * (f0 + 2.f * img1[o] * f1 + img2[o] * f2);
+    for (int q = 0; q < SS_T * SS_T / SS_NT; q++) {
+        const int oy = ty + q * (SS_NT / SS_T);
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            f0 += w * hx[0][oy + k][tx];
+            f1 += w * hx[1][oy + k][tx];
+            f2 += w * hx[2][oy + k][tx];
+        }
+        const int x = x0 + tx, y = y0 + oy;
+        if (x < W && y < H) {
+            const size_t o = plane + (size_t)y * W + x;
+            dL_dimg1[o] = g * (f0 + 2.f * img1[o] * f1 + img2[o] * f2);
+        }
     }
 }
 
@@ -245,7 +255,7 @@ int launch_ssim_forward(int C, int H, int W, const float* img1, const float* img
                         float* dm_ds1, float* dm_ds12, float* partial, hipStream_t s) {
     const dim3 grid(ssim_tiles(W), ssim_tiles(H), C);
     StageScope st("ssim_fwd", s);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_NT), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
                        dm_ds12, partial);
     GS_LAUNCH_CHECK("ssim.forward", 0, s);
     hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)(grid.x * grid.y * grid.z),
@@ -259,7 +269,7 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
                          hipStream_t s) {
     const dim3 grid(ssim_tiles(W), ssim_tiles(H), C);
     StageScope st("ssim_bwd", s);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SS_T * SS_T), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SS_NT), 0, s, H, W, img1, img2, ssim_window(), dm_dmu1, dm_ds1,
                        dm_ds12, dL_dssim, 1.0f / ((float)C * (float)H * (float)W), dL_dimg1);
     GS_LAUNCH_CHECK("ssim.backward", 0, s);
     return GS_OK;
