@@ -42,6 +42,7 @@ __device__ __forceinline__ float ring_ror1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));
 }
 #define RING 16  // lanes per ring; a wave holds 64 / RING rings
+#define RING_STRIDE 48  // words between the rings' per-pixel constants in LDS
 
 // x[0..8] += (Gd dx, Gd dy, tdx dx, tdx dy, tdy dy, Gd, wgt gx, wgt gy, wgt gz) on the lanes of `mask`,
 // y[0..8] += the same on all other lanes: the nine instructions issued twice under complementary exec
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
-    // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row (32 words per ring) so a
-    // round's reads never wrap:  g0, g1, g2, x, y, lim
-    __shared__ float pix[6][128];
+    // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
+    // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
+    // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
+    __shared__ float pix[6][4 * RING_STRIDE];
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
             c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)j);
         }
-        const int slot = ring * 2 * RING + j;
+        const int slot = ring * RING_STRIDE + j;
         pix[0][slot] = pix[0][slot + RING] = c0.x;
         pix[1][slot] = pix[1][slot + RING] = c0.y;
         pix[2][slot] = pix[2][slot + RING] = c0.z;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     for (int c9 = 0; c9 < 9; c9++) accA[c9] = accB[c9] = 0.f;
     uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
     // index into pix[c][] of the pixel at this lane: ring base + (s - j) mod 16, + 16 within a round
-    uint32_t pidx = (uint32_t)(ring * 2 * RING + ((RING - j) & (RING - 1)));
+    uint32_t pidx = (uint32_t)(ring * RING_STRIDE + ((RING - j) & (RING - 1)));
     float pc[6];
 #pragma unroll
     for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
