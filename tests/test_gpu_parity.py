@@ -661,3 +661,47 @@ def test_end_to_end_optimisation_reduces_the_loss():
     for f in GaussianCloud.FIELDS:
         assert torch.isfinite(getattr(c, f)).all()
     assert float(stats.denom.max()) == 40.0 and float(stats.max_radii2D.max()) > 0
+
+
+@pytest.mark.gpu
+def test_random_small_scenes_against_oracle(oracle):
+    """Fuzz: 24 random small scenes (Gaussian count 1..2500, ragged image sizes down to a single tile, every SH degree,
+    all four input combinations, list lengths around the 16-entry round boundaries of the backward) -- radii exact,
+    image and all gradients within the float bar."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        n = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 200, 700, 2500]))
+        W, H = int(rng.integers(9, 150)), int(rng.integers(9, 150))
+        deg = int(rng.integers(0, 4))
+        color_mode, cov_mode = COMBOS[trial % len(COMBOS)][:2]
+        cloud, cam = helpers.cloud_and_camera(max(n, 4), W, H, sh_degree=deg, seed=100 + trial, scale_mul=float(rng.uniform(0.5, 3.0)))
+        if n < 4:
+            for f in ("xyz", "scales", "rotations", "opacity", "shs"):
+                setattr(cloud, f, getattr(cloud, f)[:n].clone())
+        bg = tuple(float(v) for v in rng.random(3))
+        sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode)
+        fw = oracle.forward(sc)
+        gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(trial))
+        want = oracle.backward(sc, fw, gimg.numpy())
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, color_mode, cov_mode, dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(cloud.xyz.shape[0], 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        color, radii = GaussianRasterizer(_settings(cam, cloud, bg, dev))(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        (color * gimg.to(dev)).sum().backward()
+        tag = "trial %d (n=%d %dx%d deg %d %s/%s)" % (trial, n, W, H, deg, color_mode, cov_mode)
+        assert np.array_equal(radii.cpu().numpy(), fw["radii"]), tag
+        _bulk_close(color.detach().cpu().numpy(), fw["color"], frac=1e-3, name=tag + " color")
+        names = dict(shs="sh", colors_precomp="colors_precomp", scales="scales", rotations="rotations",
+                     cov3D_precomp="cov3D_precomp")
+        got = dict(means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad)
+        for k, v in kw.items():
+            got[names[k]] = v.grad
+        for name, gt in got.items():
+            w = want[name].reshape(gt.shape)
+            if np.abs(w).max() == 0:
+                assert np.abs(gt.cpu().numpy()).max() == 0, tag + " " + name
+                continue
+            _bulk_close(gt.cpu().numpy(), w, tol=5e-5, frac=2e-3, name=tag + " " + name)
