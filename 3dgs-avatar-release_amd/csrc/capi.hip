@@ -232,8 +232,6 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
     const int64_t D = *word;
     *num_rendered = D;
     if (D > (int64_t)GS_MAX_PAIRS) return GS_E_TOO_LARGE;
-    const ImgLayout I = img_layout(a->W, a->H);
-    (void)I;
     if (D > 0 && (!binning || binning_bytes < bin_layout(D).total)) return GS_E_WORKSPACE;  // caller sizes it, then phase 2
     return gs_forward_render(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream);
 }

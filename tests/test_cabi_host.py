@@ -71,3 +71,34 @@ def test_argument_validation_without_a_device(lib):
     assert L.gs_forward_preprocess(ctypes.byref(a), fake, 16, fake, 1 << 30, fake, None, None) == -5  # workspace too small
     with pytest.raises(RuntimeError, match="exactly one of"):
         lib.check(-2)
+
+
+def test_neighbouring_entry_points_validate_on_the_host(lib):
+    """The N2-N4 entry points (losses, pre-pass, knn_points, optimiser) reject bad arguments before any HIP call."""
+    L = lib.load()
+    fake = 0x1000  # 16-byte aligned, never dereferenced
+    out = ctypes.c_size_t(0)
+    assert L.gs_l1_loss_workspace_bytes(1024 * 1024 * 3, ctypes.byref(out)) == 0 and out.value >= 4
+    assert L.gs_l1_loss(0, fake, fake, fake, fake, fake, 1 << 20, None) == -1          # n must be positive
+    assert L.gs_l1_loss(16, fake + 4, fake, fake, fake, fake, 1 << 20, None) == -1     # float4 alignment
+    assert L.gs_l1_loss(1 << 24, fake, fake, fake, fake, fake, 4, None) == -5          # workspace too small
+    assert L.gs_ssim_workspace_bytes(3, 64, 0, ctypes.byref(out)) == -1
+    assert L.gs_ssim_forward(3, 64, 64, fake, fake, fake, fake, None, None, fake, 1 << 20, None) == -1  # maps: all or none
+    assert L.gs_ssim_forward(3, 64, 64, fake, fake, fake, None, None, None, fake, 4, None) == -5
+    assert L.gs_ssim_backward(3, 64, 64, fake, fake, fake, fake, fake, None, fake, None) == -1
+    assert L.gs_build_covariance(10, fake, 1.0, fake + 4, 0, fake, None) == -1          # quaternions read as float4
+    assert L.gs_build_covariance(-1, fake, 1.0, fake, 1, fake, None) == -1
+    assert L.gs_sh2rgb(10, 3, 9, fake, fake, fake, None, None, fake, fake, None) == -1  # degree 3 needs 16 coefficients
+    assert L.gs_sh2rgb(10, 4, 16, fake, fake, fake, None, None, fake, fake, None) == -1
+    assert L.knn_points(10, fake, 10, fake, 9, fake, fake, fake, 1 << 20, None) == -1   # K <= 8
+    assert L.knn_points(10, fake, 0, fake, 1, fake, fake, fake, 1 << 20, None) == -1    # empty reference set
+    t = (lib.GsAdamTensor * 1)(lib.GsAdamTensor(fake, fake, None, fake, 10, 1e-3))
+    assert L.gs_adam_step(1, t, 0.9, 0.999, 1e-15, 1, None) == -1                      # missing state tensor
+    t[0].exp_avg = fake
+    assert L.gs_adam_step(1, t, 0.9, 0.999, 1e-15, 0, None) == -1                      # step numbers start at 1
+    assert L.gs_adam_step(17, t, 0.9, 0.999, 1e-15, 1, None) == -1                     # more than GS_ADAM_MAX_TENSORS
+    assert L.gs_densify_stats(5, None, fake, fake, fake, fake, None) == -1
+    # empty inputs are fine and touch nothing
+    assert L.gs_build_covariance(0, None, 1.0, None, 0, None, None) == 0
+    assert L.gs_adam_step(0, None, 0.9, 0.999, 1e-15, 1, None) == 0
+    assert L.gs_densify_stats(0, None, None, None, None, None, None) == 0
