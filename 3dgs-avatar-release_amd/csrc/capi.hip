@@ -281,9 +281,19 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     return GS_OK;
 }
 
-int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
-                size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
-                const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {
+int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, float* opacity, void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!img || !opacity) return GS_E_BAD_ARG;
+    const ImgLayout I = img_layout(a->W, a->H);
+    if (img_bytes < I.total) return GS_E_WORKSPACE;
+    return launch_opacity_image((const float*)((const char*)img + I.final_T), a->bg, a->W, a->H, opacity, (hipStream_t)stream);
+}
+
+static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+                         size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
+                         const float* dL_dpix, const float* dL_dopacity_img, void* scratch, size_t scratch_bytes,
+                         const GsGrads* gr, void* stream) {
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch)) return GS_E_BAD_ARG;
@@ -319,7 +329,8 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
-                                    out_color, dL_dpix, (float*)scratch, q8, s); }
+                                    out_color, dL_dpix, dL_dopacity_img, (const float*)(im + I.final_T), a->bg, (float*)scratch, q8,
+                                    s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -331,6 +342,22 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
                                     (const uint32_t*)(g + L.clamped), (const uint32_t*)((const char*)scratch + scratch_rows_bytes(D)),
                                     (const float*)scratch,
                                     (float*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D)), *gr, s);
+}
+
+int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+                size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
+                const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {
+    return backward_impl(a, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, dL_dpix, nullptr,
+                         scratch, scratch_bytes, gr, stream);
+}
+
+int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
+                             const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                             const float* out_color, const float* dL_dpix, const float* dL_dopacity_img, void* scratch,
+                             size_t scratch_bytes, const GsGrads* gr, void* stream) {
+    if (!dL_dopacity_img) return GS_E_BAD_ARG;
+    return backward_impl(a, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, dL_dpix,
+                         dL_dopacity_img, scratch, scratch_bytes, gr, stream);
 }
 
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

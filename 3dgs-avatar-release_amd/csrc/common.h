@@ -205,8 +205,10 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
                           const QuadLists& ql, hipStream_t s);
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
-                           const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           uint32_t* q8, hipStream_t s);
+                           const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
+                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s);
+// opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
+int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s);

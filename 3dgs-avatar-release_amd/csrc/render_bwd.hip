@@ -89,6 +89,10 @@ struct Entry {
     float x, y, A2, B2, C2, o, r, g, b;
 };
 
+// OPA: the image has a fourth channel whose "colour" is 1 for every Gaussian -- the opacity render the reference
+// obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
+// that channel: one more term in (c . g) and in Gtot, nothing else changes.
+template <bool OPA>
 __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order, int W, int H, int gx,
@@ -97,13 +101,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const uint32_t* __restrict__ qcount,
                                                         const float* __restrict__ out_color,
                                                         const float* __restrict__ dL_dpix,
+                                                        const float* __restrict__ dL_dopa,
+                                                        const float* __restrict__ final_T, const float* __restrict__ bg,
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
     // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
-    __shared__ float pix[6][4 * RING_STRIDE];
+    __shared__ float pix[OPA ? 7 : 6][4 * RING_STRIDE];  // (+ the opacity channel's gradient)
     const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int q = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -128,6 +134,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float g0 = dL_dpix[pid], g1 = dL_dpix[HW + pid], g2 = dL_dpix[2 * HW + pid];
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
             c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)j);
+            if (OPA) {
+                const float Tf = final_T[pid];
+                c1.w = dL_dopa[pid];
+                c0.w += ((1.0f - Tf) + Tf * bg[0]) * c1.w;  // the opacity channel's share of Gtot
+            }
         }
         const int slot = ring * RING_STRIDE + j;
         pix[0][slot] = pix[0][slot + RING] = c0.x;
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         pix[3][slot] = pix[3][slot + RING] = c1.x;
         pix[4][slot] = pix[4][slot + RING] = c1.y;
         pix[5][slot] = pix[5][slot + RING] = c1.z;
+        if (OPA) pix[6][slot] = pix[6][slot + RING] = c1.w;
         gtot0 = c0.w;
     }
 
@@ -179,9 +191,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
     // index into pix[c][] of the pixel at this lane: ring base + (s - j) mod 16, + 16 within a round
     uint32_t pidx = (uint32_t)(ring * RING_STRIDE + ((RING - j) & (RING - 1)));
-    float pc[6];
+    constexpr int NPC = OPA ? 7 : 6;
+    float pc[NPC];
 #pragma unroll
-    for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
+    for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
     // (position i of a ring starts at ring lane (16 - i) mod 16; fetch its Gtot from the lane that loaded it)
     float T = 1.0f, Rem = __shfl(gtot0, ring * RING + ((RING - j) & (RING - 1)), 64);
@@ -230,10 +243,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[3], pyf = pc[4];
             const uint32_t lim = __float_as_uint(pc[5]);
+            const float g4 = OPA ? pc[NPC - 1] : 0.f;
             // next step's pixel constants, fetched now
             pidx += 1u;
 #pragma unroll
-            for (int c6 = 0; c6 < 6; c6++) pc[c6] = pix[c6][pidx];
+            for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
             const float dx = cur.x - pxf, dy = cur.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
             const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float alpha = valid ? a2 : 0.f;
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
-            const float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
+            const float cg = OPA ? (cur.r * g.x + cur.g * g.y + cur.b * g.z) + g4 : cur.r * g.x + cur.g * g.y + cur.b * g.z;
             Rem = __builtin_fmaf(-cg, wgt, Rem);
             const float one_m = 1.f - alpha;
             const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
@@ -292,12 +306,17 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 }
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
-                           const QuadLists& ql, const float* out_color, const float* dL_dpix, float* qrows,
-                           uint32_t* q8, hipStream_t s) {
+                           const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
+                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                       reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
-                       out_color, dL_dpix, reinterpret_cast<float4*>(qrows), q8);
+    if (dL_dopa)
+        hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
+                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
+                           out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
+    else
+        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
+                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
+                           out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

@@ -141,3 +141,21 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }
+
+// The opacity render -- what a second rasterizer call with colours = 1 returns in every channel
+// (gaussian_renderer/__init__.py:132-142): sum_i alpha_i T_i + T_final * bg = (1 - T_final) + T_final * bg[0].
+// The forward already has T_final per pixel, so no second render is needed.
+__global__ __launch_bounds__(256) void opacity_image_kernel(const float* __restrict__ final_T, const float* __restrict__ bg,
+                                                            int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float Tf = final_T[i];
+    out[i] = (1.0f - Tf) + Tf * bg[0];
+}
+
+int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s) {
+    const int n = W * H;
+    hipLaunchKernelGGL(opacity_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, final_T, bg, n, out);
+    GS_LAUNCH_CHECK("opacity_image", 0, s);
+    return GS_OK;
+}

@@ -134,15 +134,19 @@ def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotatio
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                        raster_settings, with_opacity=False):
+    """(color, radii), as upstream.  with_opacity=True (an extension; see GaussianRasterizer.forward) adds the
+    opacity render as a third result, computed and differentiated inside the same pass."""
+    color, radii, opacity = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                                       cov3Ds_precomp, raster_settings, bool(with_opacity))
+    return (color, radii, opacity) if with_opacity else (color, radii)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, with_opacity=False):
+        ctx.with_opacity = bool(with_opacity)
         L = _lib.load()
         means3D = _f32c(means3D, "means3D")
         if means3D is None:
@@ -181,7 +185,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                img_bytes, num_rendered, color.data_ptr(), sptr))
                 return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
-                                                   img, color, dev)
+                                                   img, color, dev, a, sptr)
             count = _pinned_count(dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
@@ -207,12 +211,20 @@ class _RasterizeGaussians(torch.autograd.Function):
                 bin_bytes = 0
             if _SHARE:
                 _geom_cache.store(dev, gkey, geom=geom, binning=binning, img=img, num_rendered=num_rendered, radii=radii)
-        return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,
-                                           scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color, dev)
+            return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,
+                                               scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color, dev, a,
+                                               sptr)
 
     @staticmethod
     def _finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, radii, geom, binning, img, color, dev):
+                cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr):
+        opacity = None
+        if ctx.with_opacity:
+            # the opacity render is (1 - final_T) + final_T * bg[0]: the forward that just ran holds final_T
+            L = _lib.load()
+            H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+            opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            _lib.check(L.gs_opacity_image(ctypes.byref(a), img.data_ptr(), img.numel(), opacity.data_ptr(), sptr))
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -222,10 +234,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                               scales if scales is not None else empty, rotations if rotations is not None else empty,
                               cov3Ds_precomp if cov3Ds_precomp is not None else empty, radii, geom, binning, img, color)
         ctx.mark_non_differentiable(radii)
-        return color, radii
+        return color, radii, opacity
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
+    def backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
         L = _lib.load()
         (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
          color) = ctx.saved_tensors
@@ -235,7 +247,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         W, H = int(settings.image_width), int(settings.image_height)
         D = ctx.num_rendered
+        if grad_out_color is None:  # only the opacity render was used downstream
+            grad_out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         g = _f32c(grad_out_color, "grad_out_color")
+        g_op = _f32c(grad_out_opacity, "grad_out_opacity") if (ctx.with_opacity and grad_out_opacity is not None) else None
         keep = []
         with torch.cuda.device(dev):
             a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
@@ -256,12 +271,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = torch.empty(P, 4, **f) if has_sr else None
             gr = _lib.GsGrads(_lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_sh), _lib.ptr(d_colors),
                               _lib.ptr(d_opacity), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov3D))
-            _lib.check(L.gs_backward(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
-                                     binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
-                                     color.data_ptr(), g.data_ptr(), scratch.data_ptr(), scratch_bytes,
-                                     ctypes.byref(gr), sptr))
+            if g_op is None:
+                _lib.check(L.gs_backward(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
+                                         binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
+                                         color.data_ptr(), g.data_ptr(), scratch.data_ptr(), scratch_bytes,
+                                         ctypes.byref(gr), sptr))
+            else:
+                # the opacity render's gradient rides along as a fourth channel of the same backward pass
+                _lib.check(L.gs_backward_with_opacity(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
+                                                      binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
+                                                      color.data_ptr(), g.data_ptr(), g_op.data_ptr(), scratch.data_ptr(),
+                                                      scratch_bytes, ctypes.byref(gr), sptr))
         return (d_means3D, d_means2D, d_sh, d_colors if has_col else None, d_opacity, d_scales, d_rot,
-                d_cov3D if has_cov else None, None)
+                d_cov3D if has_cov else None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -285,7 +307,10 @@ class GaussianRasterizer(nn.Module):
         return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, with_opacity=False):
+        """Upstream signature and results: (color[3,H,W], radii[N]).  `with_opacity=True` is an extension: a third
+        result, the opacity render [1,H,W] -- what the reference gets from a second call with colours = 1
+        (gaussian_renderer/__init__.py:132-142, `[:1]`) -- produced and differentiated inside the same pass."""
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -303,4 +328,4 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings)
+                                   raster_settings, with_opacity=with_opacity)

@@ -30,7 +30,8 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
-           "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step"]
+           "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
+           "gs_opacity_image", "gs_backward_with_opacity"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_ADAM_MAX_TENSORS = 16
@@ -72,6 +73,10 @@ def load():
                                         c_void_p, c_size_t, c_int64, c_void_p, c_void_p]
         L.gs_backward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
                                   c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(GsGrads), c_void_p]
+        L.gs_opacity_image.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_void_p]
+        L.gs_backward_with_opacity.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                                               c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(GsGrads),
+                                               c_void_p]
         L.gs_mark_visible.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.knn_workspace_bytes.argtypes = [c_int32, POINTER(c_size_t)]
         L.knn_dist2.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]

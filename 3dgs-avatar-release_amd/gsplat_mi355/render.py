@@ -17,10 +17,13 @@ from . import _lib
 class Pipe(object):
     """pipeline.* keys the renderer reads (configs/config.yaml:89-92)."""
 
-    def __init__(self, compute_cov3D_python=False, convert_SHs_python=False, debug=False):
+    def __init__(self, compute_cov3D_python=False, convert_SHs_python=False, debug=False, fuse_opacity=False):
         self.compute_cov3D_python = compute_cov3D_python
         self.convert_SHs_python = convert_SHs_python
         self.debug = debug
+        # not a reference key: render the opacity image inside the colour pass (one rasterizer call with
+        # with_opacity=True) instead of the reference's second call with colours = 1
+        self.fuse_opacity = fuse_opacity
 
 
 class RenderPackage(object):
@@ -73,11 +76,17 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
         colors_precomp = sh2rgb(pc.shs, xyz, data.camera_center, pc.sh_degree,
                                 fwd_transform=getattr(pc, "fwd_transform", None))
     shs = None if colors_precomp is not None else pc.shs
-    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                       opacities=opacity, scales=scales, rotations=rotations,
-                                       cov3D_precomp=cov3D_precomp)
     opacity_image = None
-    if return_opacity:
+    if return_opacity and getattr(pipe, "fuse_opacity", False):
+        rendered_image, radii, opacity_image = rasterizer(means3D=means3D, means2D=means2D, shs=shs,
+                                                          colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+                                                          rotations=rotations, cov3D_precomp=cov3D_precomp,
+                                                          with_opacity=True)
+    else:
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                           opacities=opacity, scales=scales, rotations=rotations,
+                                           cov3D_precomp=cov3D_precomp)
+    if return_opacity and opacity_image is None:
         opacity_image, _ = rasterizer(means3D=means3D, means2D=means2D, shs=None,
                                       colors_precomp=torch.ones(opacity.shape[0], 3, device=opacity.device),
                                       opacities=opacity, scales=scales, rotations=rotations,

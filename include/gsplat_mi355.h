@@ -128,6 +128,20 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
                 const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,
                 const GsGrads* grads, void* stream);
 
+/* ---- opacity render fused into the colour render (second form).  The reference obtains
+ * its opacity image with a SECOND rasterizer call with colours = 1 (gaussian_renderer/__init__.py:132-142; used by
+ * the mask loss, train.py:143-153, lambda_mask = 0.1 in configs/config.yaml).  That image is
+ * (1 - final_T) + final_T * bg[0] per pixel and the forward already holds final_T: gs_opacity_image writes it
+ * ([H,W] floats) from the image state of a finished forward, and gs_backward_with_opacity takes the gradient of
+ * that image as a fourth channel of the same backward pass (its background value is bg[0], as in the reference) --
+ * one render and one backward instead of two of each. ---- */
+int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, float* opacity, void* stream);
+int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
+                             const void* binning, size_t binning_bytes, const void* img, size_t img_bytes,
+                             int64_t num_rendered, const float* out_color, const float* dL_dpix,
+                             const float* dL_dopacity_img, void* scratch, size_t scratch_bytes, const GsGrads* grads,
+                             void* stream);
+
 /* ---- upstream mark_visible / GaussianRasterizer.markVisible: present[i] = (z_view > 0.2) ---- */
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);

@@ -705,3 +705,54 @@ def test_random_small_scenes_against_oracle(oracle):
                 assert np.abs(gt.cpu().numpy()).max() == 0, tag + " " + name
                 continue
             _bulk_close(gt.cpu().numpy(), w, tol=5e-5, frac=2e-3, name=tag + " " + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bgval", [(0.0, 0.0, 0.0), (0.3, 0.6, 0.1)])
+def test_fused_opacity_render_matches_the_second_rasterizer_call(oracle, bgval):
+    """N1, second form: rasterizer(..., with_opacity=True) returns the image the reference gets from its second call
+    with colours = 1 (`[:1]`, gaussian_renderer/__init__.py:132-142) and its backward returns the SUM of the two calls'
+    gradients -- compared with the two-call path of this library (itself checked against the oracle) and with the
+    oracle's opacity render."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 3000, 150, 110
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=13, scale_mul=1.2)
+    gen = torch.Generator().manual_seed(8)
+    gimg = torch.randn(3, H, W, generator=gen).to(dev)
+    gop = torch.randn(1, H, W, generator=gen).to(dev)
+    rast = GaussianRasterizer(_settings(cam, cloud, bgval, dev))
+
+    def leaves():
+        return dict(means3D=cloud.xyz.to(dev).clone().requires_grad_(True),
+                    means2D=torch.zeros(n, 3, device=dev, requires_grad=True),
+                    opacities=cloud.opacity.to(dev).clone().requires_grad_(True),
+                    shs=cloud.shs.to(dev).clone().requires_grad_(True),
+                    scales=cloud.scales.to(dev).clone().requires_grad_(True),
+                    rotations=cloud.rotations.to(dev).clone().requires_grad_(True))
+
+    a = leaves()
+    color, radii, opa = rast(with_opacity=True, **a)
+    ((color * gimg).sum() + (opa * gop).sum()).backward()
+    b = leaves()
+    color2, radii2 = rast(**b)
+    opa2, _ = rast(means3D=b["means3D"], means2D=b["means2D"], opacities=b["opacities"], shs=None,
+                   colors_precomp=torch.ones(n, 3, device=dev), scales=b["scales"], rotations=b["rotations"])
+    ((color2 * gimg).sum() + (opa2[:1] * gop).sum()).backward()
+    assert torch.equal(color, color2) and torch.equal(radii, radii2)
+    assert np.abs((opa - opa2[:1]).detach().cpu().numpy()).max() <= 2e-6
+    sc = helpers.oracle_scene(cloud, cam, bg=bgval, color_mode="precomp", cov_mode="scale_rot", colors=torch.ones(n, 3))
+    assert np.abs(opa[0].detach().cpu().numpy() - oracle.forward(sc)["color"][0]).max() <= 1e-2
+    _bulk_close(opa[0].detach().cpu().numpy(), oracle.forward(sc)["color"][0], name="opacity render")
+    for k in a:
+        _bulk_close(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy(), tol=2e-5, frac=1e-4, name="fused vs two calls: " + k)
+    # only the opacity render used downstream
+    c = leaves()
+    _, _, opa3 = rast(with_opacity=True, **c)
+    (opa3 * gop).sum().backward()
+    d = leaves()
+    opa4, _ = rast(means3D=d["means3D"], means2D=d["means2D"], opacities=d["opacities"], shs=None,
+                   colors_precomp=torch.ones(n, 3, device=dev), scales=d["scales"], rotations=d["rotations"])
+    (opa4[:1] * gop).sum().backward()
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        _bulk_close(c[k].grad.cpu().numpy(), d[k].grad.cpu().numpy(), tol=2e-5, frac=1e-4, name="opacity only: " + k)

@@ -1,5 +1,7 @@
 """cost of the reference's two-render train step (colour pass + opacity pass with the
-same geometry, gaussian_renderer/__init__.py:121-142; L1 + 0.1 * mask L1) with and without geometry sharing."""
+same geometry, gaussian_renderer/__init__.py:121-142; L1 + 0.1 * mask L1): two independent rasterizer calls
+("separate"), the second call sharing the first one's geometry ("shared", transparent), and ONE call with
+with_opacity=True ("fused": the opacity render and its gradient ride along in the colour pass)."""
 import sys, time
 sys.path.insert(0, "3dgs-avatar-release_amd"); sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import torch
@@ -16,8 +18,9 @@ cams = [orbit_camera(f, W, H, device=dev) for f in range(64)]
 gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
 mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(2)) > 0.5).float().to(dev)
 bg = torch.zeros(3, device=dev)
-pipe = Pipe(compute_cov3D_python=False)
-for share in (True, False, True, False):
+for mode in ("separate", "shared", "fused", "separate", "shared", "fused"):
+    share = mode == "shared"
+    pipe = Pipe(compute_cov3D_python=False, fuse_opacity=(mode == "fused"))
     dgr._SHARE = share
     dgr._geom_cache.entry.clear()
     for i in range(5):
@@ -29,4 +32,4 @@ for share in (True, False, True, False):
         for f in GaussianCloud.FIELDS: getattr(cloud, f).grad = None
         train_step(cams[5 + i], cloud, pipe, bg, gt, gt_mask=mask, lambda_mask=0.1)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-    print("share_geometry=%s  two-render train step: %.3f ms (%.1f steps/s)" % (share, dt * 1e3, 1 / dt))
+    print("%-9s colour + opacity train step: %.3f ms (%.1f steps/s)" % (mode, dt * 1e3, 1 / dt))
