@@ -65,6 +65,10 @@ def main():
                     help="the reference's avatar call pattern: covariance from scaling + rotation_precomp (3x3) and colours "
                          "from SHs in the canonical frame computed BEFORE the rasterizer (fused N3 ops), passed as "
                          "cov3D_precomp / colors_precomp")
+    ap.add_argument("--opacity", default="none", choices=["none", "second-call", "fused"],
+                    help="also render the opacity image and add the reference's mask loss (0.1 * L1, train.py:143-153): "
+                         "second-call = the reference's second rasterizer call (served by the shared-geometry path), "
+                         "fused = rasterizer(..., with_opacity=True)")
     ap.add_argument("--train-step", action="store_true",
                     help="also run what follows the backward in the reference's step: densification statistics and the Adam "
                          "update of all parameters (fused N4 ops)")
@@ -110,7 +114,8 @@ def main():
     cams = [orbit_camera(f, W, H, device=dev) for f in frames]
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     bg = torch.zeros(3, device=dev)
-    pipe = Pipe(compute_cov3D_python=args.prepass, convert_SHs_python=args.prepass)
+    pipe = Pipe(compute_cov3D_python=args.prepass, convert_SHs_python=args.prepass, fuse_opacity=(args.opacity == "fused"))
+    gt_mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(2)) > 0.5).float().to(dev)
     if args.prepass:
         # what models/deformer/rigid.py:222-231 attaches: a (detached) forward bone transform per Gaussian and the
         # rotation matrix composed with it
@@ -132,7 +137,10 @@ def main():
     if args.train_step and do_bwd:
         from gsplat_mi355.optim import FusedAdam
         from gsplat_mi355.render import DensifyStats
-        lrs = dict(xyz=1.6e-4, scales=5e-3, rotations=1e-3, opacity=5e-2, shs=2.5e-3)  # configs/opt defaults
+        # the cloud holds POST-activation values (no log-scale / logit parametrisation), so the reference's learning
+        # rates would walk it out of the valid range within tens of steps; the cost of the update does not depend
+        # on the rate, so it is kept tiny and the scene -- hence every other stage's work -- stays what it is
+        lrs = dict(xyz=1.6e-9, scales=5e-9, rotations=1e-9, opacity=5e-9, shs=2.5e-9)
         opt = FusedAdam([{"params": [getattr(cloud, f)], "lr": lrs.get(f, 1e-3), "name": f} for f in GaussianCloud.FIELDS],
                         lr=0.0, eps=1e-15)
         stats = DensifyStats(N, dev)
@@ -143,8 +151,10 @@ def main():
         if args.prepass:
             cloud.rotation_precomp.grad = None
         if do_bwd:
-            pkg = render(cams[i], cloud, pipe, bg)
+            pkg = render(cams[i], cloud, pipe, bg, return_opacity=(args.opacity != "none"))
             loss = l1_loss(pkg.render, gt)
+            if args.opacity != "none":
+                loss = loss + 0.1 * l1_loss(pkg.opacity_render, gt_mask)
             if args.loss == "l1+dssim":  # train.py:120-124 with lambda_l1 = 0.8, lambda_dssim = 0.2
                 loss = 0.8 * loss + 0.2 * (1.0 - ssim(pkg.render, gt))
             loss.backward()
@@ -225,7 +235,8 @@ def main():
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
                 ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss") +
                 (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "") +
-                (", + densification statistics + Adam step" if args.train_step else "")),
+                (", + densification statistics + Adam step" if args.train_step else "") +
+                ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
                 "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
                 "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
                 "broadcast_s": round(t_bcast, 6)},
