@@ -425,6 +425,13 @@ int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL
     return launch_l1_loss(x, y, n, loss, dL_dx, (float*)workspace, (hipStream_t)stream);
 }
 
+int gs_bce_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace, size_t workspace_bytes,
+                void* stream) {
+    if (n <= 0 || !x || !y || !loss || !dL_dx || !workspace) return GS_E_BAD_ARG;
+    if (workspace_bytes < l1_ws_bytes(n)) return GS_E_WORKSPACE;
+    return launch_bce_loss(x, y, n, loss, dL_dx, (float*)workspace, (hipStream_t)stream);
+}
+
 int gs_ssim_workspace_bytes(int32_t C, int32_t H, int32_t W, size_t* out) {
     if (!out || C <= 0 || H <= 0 || W <= 0) return GS_E_BAD_ARG;
     *out = ssim_ws_bytes(C, H, W);

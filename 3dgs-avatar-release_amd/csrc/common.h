@@ -185,6 +185,7 @@ int launch_sh2rgb_bwd(int N, int deg, int M, const float* shs, const float* xyz,
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
 size_t l1_ws_bytes(int64_t n);
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
+int launch_bce_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
 // SSIM of two (C,H,W) images + the three partial-derivative maps its backward filters (loss.hip)
 size_t ssim_ws_bytes(int C, int H, int W);
 int launch_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_out, float* dm_dmu1,

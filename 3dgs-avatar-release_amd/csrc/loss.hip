@@ -54,12 +54,47 @@ __global__ __launch_bounds__(L1_THREADS) void l1_final_kernel(const float* __res
     if (tid == 0) loss[0] = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_n;
 }
 
+// Mask loss, BCE form (train.py:146-148): F.binary_cross_entropy(torch.clamp(x, 1e-3, 1 - 1e-3), y), mean over all
+// elements, and its gradient w.r.t. x: (p - y) / (p (1 - p)) / n inside the clamp range, 0 outside.  Same
+// two-stage ordered reduction as the L1 loss.
+__global__ __launch_bounds__(L1_THREADS) void bce_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                 int64_t n, float inv_n, float* __restrict__ grad,
+                                                                 float* __restrict__ partial) {
+    __shared__ float ws[L1_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * L1_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * L1_THREADS + tid; i < n; i += stride) {
+        const float xv = x[i], t = y[i];
+        const float p = fminf(fmaxf(xv, 1.0e-3f), 1.0f - 1.0e-3f);
+        acc -= t * logf(p) + (1.0f - t) * logf(1.0f - p);
+        const bool inside = xv >= 1.0e-3f && xv <= 1.0f - 1.0e-3f;  // clamp passes the gradient on its closed range
+        grad[i] = inside ? (p - t) / (p * (1.0f - p)) * inv_n : 0.f;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    if (lane == 0) ws[wid] = acc;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 static int l1_blocks(int64_t n) {
     const int64_t want = ((n >> 2) + L1_THREADS - 1) / L1_THREADS;
     return (int)(want < 1 ? 1 : (want > L1_MAX_BLOCKS ? L1_MAX_BLOCKS : want));
 }
 
 size_t l1_ws_bytes(int64_t n) { return (size_t)l1_blocks(n) * sizeof(float); }
+
+int launch_bce_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s) {
+    const int blocks = l1_blocks(n);
+    const float inv_n = 1.0f / (float)n;
+    StageScope st("bce_loss", s);
+    hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(L1_THREADS), 0, s, x, y, n, inv_n, grad, partial);
+    GS_LAUNCH_CHECK("bce_loss.partial", 0, s);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, partial, blocks, inv_n, loss);
+    GS_LAUNCH_CHECK("bce_loss.final", 0, s);
+    return GS_OK;
+}
 
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s) {
     const int blocks = l1_blocks(n);

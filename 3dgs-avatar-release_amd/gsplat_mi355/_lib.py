@@ -29,7 +29,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_forward_preprocess", "gs_forward_render", "gs_forward", "gs_forward_shared", "gs_backward", "gs_mark_visible", "knn_workspace_bytes",
            "knn_dist2", "gs_geom_field", "gs_binning_field", "gs_image_field", "gs_status_string",
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
-           "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
+           "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
            "gs_opacity_image", "gs_backward_with_opacity"]
 
@@ -82,6 +82,7 @@ def load():
         L.knn_dist2.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.gs_l1_loss_workspace_bytes.argtypes = [c_int64, POINTER(c_size_t)]
         L.gs_l1_loss.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.gs_bce_loss.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.gs_ssim_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, POINTER(c_size_t)]
         L.gs_ssim_forward.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_size_t, c_void_p]

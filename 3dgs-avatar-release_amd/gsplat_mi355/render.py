@@ -120,6 +120,41 @@ class _L1Loss(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None), (-gx if ctx.needs_input_grad[1] else None)
 
 
+class _BceLoss(torch.autograd.Function):
+    """mean BCE of clamp(x, 1e-3, 1 - 1e-3) against y with d/dx from the same HIP pass (gs_bce_loss)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        L = _lib.load()
+        n = x.numel()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        ws = torch.empty(_lib.nbytes(L.gs_l1_loss_workspace_bytes, n), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            sptr = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(L.gs_bce_loss(n, x.data_ptr(), y.data_ptr(), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), sptr))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def bce_mask_loss(opacity, gt_mask):
+    """train.py:146-148: F.binary_cross_entropy(torch.clamp(opacity, 1e-3, 1 - 1e-3), gt_mask) as one fused HIP pass
+    (the 'bce' form of the mask loss; the default 'l1' form is `l1_loss`).  The mask gets no gradient."""
+    if not (opacity.is_cuda and gt_mask.is_cuda):
+        raise RuntimeError("bce_mask_loss: both tensors must live on the GPU (no CPU fallback)")
+    if opacity.dtype != torch.float32 or gt_mask.dtype != torch.float32:
+        raise TypeError("bce_mask_loss: fp32 tensors expected")
+    if opacity.shape != gt_mask.shape or opacity.numel() == 0:
+        raise ValueError("bce_mask_loss: equal, non-empty shapes expected")
+    return _BceLoss.apply(opacity.contiguous(), gt_mask.contiguous())
+
+
 def l1_loss(network_output, gt):
     """torch.abs(network_output - gt).mean() of utils/loss_utils.py:21-22 as ONE fused HIP pass
     (SURVEY.md 8f row N2).  Device fp32 tensors only: there is no CPU path."""

@@ -183,6 +183,12 @@ int gs_l1_loss_workspace_bytes(int64_t n, size_t* out);
 int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* Mask loss, BCE form (train.py:146-148, mask_loss_type = 'bce'; the 'l1' form is gs_l1_loss):
+ * loss[0] = mean of binary_cross_entropy(clamp(x, 1e-3, 1 - 1e-3), y), dL_dx its gradient w.r.t. x (zero where the
+ * clamp is active).  Workspace: gs_l1_loss_workspace_bytes(n). */
+int gs_bce_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 /* SSIM half of row N2: utils/loss_utils.py:27-67 `ssim(img1, img2)` (window 11, sigma 1.5, zero padding,
  * C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W elements; train.py:123 uses 1 - ssim as the D-SSIM loss).
  * gs_ssim_forward writes ssim_out[0] and, when the three map pointers are non-NULL (all or none), the

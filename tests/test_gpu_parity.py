@@ -756,3 +756,28 @@ def test_fused_opacity_render_matches_the_second_rasterizer_call(oracle, bgval):
     (opa4[:1] * gop).sum().backward()
     for k in ("means3D", "opacities", "scales", "rotations"):
         _bulk_close(c[k].grad.cpu().numpy(), d[k].grad.cpu().numpy(), tol=2e-5, frac=1e-4, name="opacity only: " + k)
+
+
+@pytest.mark.gpu
+def test_fused_bce_mask_loss_matches_torch():
+    """N2: gsplat_mi355.render.bce_mask_loss == F.binary_cross_entropy(torch.clamp(opacity, 1e-3, 1 - 1e-3), mask)
+    (train.py:146-148), pinned against torch's own float64 evaluation on the CPU: value 1e-6 relative, gradient 1e-5
+    of its maximum, zero gradient where the clamp is active."""
+    import torch.nn.functional as F
+    from gsplat_mi355.render import bce_mask_loss
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(1, 97, 131, generator=g)
+    x.view(-1)[:50] = 0.0      # below the clamp
+    x.view(-1)[50:100] = 1.0   # above the clamp
+    y = (torch.rand(1, 97, 131, generator=g) > 0.4).float()
+    xd = x.double().requires_grad_(True)
+    ref = F.binary_cross_entropy(torch.clamp(xd, 1.0e-3, 1.0 - 1.0e-3), y.double())
+    (3.0 * ref).backward()
+    xg = x.cuda().requires_grad_(True)
+    loss = bce_mask_loss(xg, y.cuda())
+    (3.0 * loss).backward()
+    assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-6)
+    want = xd.grad.numpy()
+    got = xg.grad.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.all(got.reshape(-1)[:100] == 0)
