@@ -29,6 +29,7 @@ struct ProfState {
 // process-wide (autograd runs the backward on its own host thread), guarded by a mutex
 #include <mutex>
 #include <chrono>
+#include <atomic>
 static ProfState g_prof;
 static std::mutex g_prof_mu;
 void gs_prof_begin(const char* stage, hipStream_t s) {
@@ -211,7 +212,8 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
     // idles.)  The poll is bounded; past the bound, or without Gaussians, the stream is synchronised instead.
     volatile int64_t* word = count_host_pinned;
     const int64_t pending = -1;
-    const bool poll = a && a->P > 0;
+    static std::atomic<bool> poll_works{true};  // cleared for the process if a device write to the word is ever not seen
+    const bool poll = a && a->P > 0 && poll_works.load(std::memory_order_relaxed);
     if (poll) *word = pending;
     int rc = forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned,
                             poll ? (unsigned long long*)count_host_pinned : nullptr, stream);
@@ -225,9 +227,17 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
         }
     }
     if (!have) {
-        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) { gs_set_error((int)e, "count.sync"); return GS_E_HIP; }
-        if (poll && *word == pending) { gs_set_error(0, "count.poll"); return GS_E_HIP; }
+        if (poll && *word == pending) {
+            // the host word is not device-visible memory on this system: read the count from the geom state and
+            // use the copy + synchronise form from now on
+            poll_works.store(false, std::memory_order_relaxed);
+            int64_t c = 0;
+            e = hipMemcpy(&c, (const char*)geom + geom_layout(a->P).count, 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { gs_set_error((int)e, "count.copy"); return GS_E_HIP; }
+            *word = c;
+        }
     }
     const int64_t D = *word;
     *num_rendered = D;
