@@ -86,6 +86,28 @@ __device__ __forceinline__ void cov2d(const float3 mean, float fx, float fy, flo
     ratios[0] = txtz; ratios[1] = tytz;
 }
 
+// An upper bound of ln(x) for x >= 1 from exactly rounded IEEE operations only (no libm: the tile rectangle it
+// feeds must be bit-identical on the CPU oracle): x = m 2^e with m in [1,2); ln m <= m - 1 (tangent at 1) and
+// ln m <= ln 1.5 + (m - 1.5) / 1.5 (tangent at 1.5); at most 0.095 above ln x.
+__device__ __forceinline__ float ln_upper_bound(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const int e = (int)(u >> 23) - 127;
+    const float m = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
+    const float lm = (m < 1.5f) ? (m - 1.0f) : (0.405465126f + (m - 1.5f) * 0.666666687f);
+    return (float)e * 0.693147182f + lm;
+}
+
+// Half-widths of the axis-aligned bounding box of { alpha >= 1/255 } = { d^T Sigma^-1 d <= 2 ln(255 opacity) } for
+// the 2-D covariance (a, b, c): sqrt(thr a), sqrt(thr c).  Returns false when alpha stays below 1/255 everywhere.
+__device__ __forceinline__ bool snug_half_widths(float opacity, float cov_a, float cov_c, float* hx, float* hy) {
+    const float x = 255.0f * opacity;
+    if (!(x >= 1.0f)) return false;
+    const float thr = 2.0f * ln_upper_bound(x) + 0.002f;  // + margin for the rounding of the per-pixel test
+    *hx = fminf(sqrtf(thr * cov_a), 1.0e7f);
+    *hy = fminf(sqrtf(thr * cov_c), 1.0e7f);
+    return true;
+}
+
 // SH -> RGB for a UNIT direction (x, y, z) (utils/sh_utils.py:58-101 polynomial; +0.5; clamp at 0 recorded
 // as bit c of *clamped).  sh points at this Gaussian's (M,3) block.
 __device__ __forceinline__ float3 sh_eval_dir(int deg, const float x, const float y, const float z,

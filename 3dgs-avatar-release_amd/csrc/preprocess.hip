@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy,
+    int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy, int tile_rect,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii, ZeroJob zero) {
     zero_job(zero);  // the depth sort's digit totals (saves a fill launch)
@@ -84,8 +84,26 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             miny = min(gy, max(0, miny));
             maxx = min(gx, max(0, maxx));
             maxy = min(gy, max(0, maxy));
-            const int w = maxx - minx, h = maxy - miny;
+            int w = maxx - minx, h = maxy - miny;
             if (w * h != 0) {
+                if (tile_rect) {
+                    // bin into the bounding box of the alpha >= 1/255 region only (GsFwdArgs.tile_rect = 1); the
+                    // Gaussian stays "visible" (radii, colour, depth) exactly as with the square
+                    float hx, hy;
+                    if (snug_half_widths(opacities[i], cov[0], cov[2], &hx, &hy)) {
+                        minx = max(minx, (int)((px - hx) / TILE));
+                        miny = max(miny, (int)((py - hy) / TILE));
+                        maxx = min(maxx, (int)((px + hx) / TILE) + 1);
+                        maxy = min(maxy, (int)((py + hy) / TILE) + 1);
+                        if (maxx < minx) maxx = minx;
+                        if (maxy < miny) maxy = miny;
+                    } else {
+                        maxx = minx;
+                        maxy = miny;
+                    }
+                    w = maxx - minx;
+                    h = maxy - miny;
+                }
                 float3 col;
                 if (colors_precomp) {
                     col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
@@ -125,6 +143,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.scales,
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
+                       a.tile_rect,
                        rec, depths, tiles, clamped, sort_keys, sort_vals, radii, zero);
     GS_LAUNCH_CHECK("preprocess", a.debug, s);
     return GS_OK;

@@ -57,7 +57,7 @@ class _GeomCache(object):
 
     def key(self, settings, means3D, opacities, scales, rotations, cov3D):
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
-                             float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0])),
+                             float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT),
                     tensors=[self._sig(t) for t in (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix,
                                                     settings.projmatrix, settings.campos)])
 
@@ -105,6 +105,11 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+# Which tiles a Gaussian is binned into (GsFwdArgs.tile_rect): 1 = the bounding box of its alpha >= 1/255 region
+# (default: same outputs, ~40 % fewer (tile, Gaussian) pairs), 0 = upstream's 3-sigma square (GSPLAT_TILE_RECT=0).
+_TILE_RECT = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
+
+
 def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep):
     a = _lib.GsFwdArgs()
     P = int(means3D.shape[0])
@@ -130,6 +135,7 @@ def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotatio
     a.tanfovx, a.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
     a.prefiltered = int(bool(settings.prefiltered))
     a.debug = int(bool(settings.debug))
+    a.tile_rect = _TILE_RECT
     return a
 
 

@@ -16,7 +16,7 @@ class GsFwdArgs(ctypes.Structure):
         ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p),
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("campos", c_void_p),
         ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
-        ("prefiltered", c_int32), ("debug", c_int32),
+        ("prefiltered", c_int32), ("debug", c_int32), ("tile_rect", c_int32),
     ]
 
 

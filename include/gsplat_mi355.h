@@ -62,6 +62,11 @@ typedef struct GsFwdArgs {
     float scale_modifier, tanfovx, tanfovy;
     int32_t prefiltered; /* accepted for API parity; culled points are skipped either way */
     int32_t debug;       /* !=0: synchronise + check after every kernel, name the failing stage */
+    int32_t tile_rect;   /* which tiles a Gaussian is binned into.  0: upstream's square of half-width ceil(3 sigma_max)
+                          * around the centre.  1: the bounding box of the region where its alpha can reach 1/255
+                          * (half-widths sqrt(2 ln(255 opacity) Sigma_xx), sqrt(... Sigma_yy)), intersected with the
+                          * square: every tile left out contributes nothing to any pixel, so colour, radii and all
+                          * gradients are those of mode 0 while num_rendered and the tile lists are ~40 % shorter */
 } GsFwdArgs;
 
 /* The eight gradient outputs of upstream `rasterize_gaussians_backward`, in the order the

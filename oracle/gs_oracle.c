@@ -51,6 +51,7 @@ typedef struct {
         *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tanfovx, tanfovy;
     int prefiltered;
+    int tile_rect; /* 0: upstream's 3-sigma square; 1: bounding box of the alpha >= 1/255 region (see or_preprocess) */
 } OrArgs;
 
 /* p_view = [p,1] @ viewmatrix (row-vector convention, flat index = row*4 + col):
@@ -215,6 +216,34 @@ int or_preprocess(const OrArgs* a, float* depths, int* radii, float* xy, float* 
         maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
         maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
         if ((maxx - minx) * (maxy - miny) == 0) continue;
+        if (a->tile_rect) {
+            /* Not upstream: bin into the axis-aligned bounding box of { alpha >= 1/255 } =
+             * { d^T Sigma^-1 d <= 2 ln(255 opacity) } only -- half-widths sqrt(thr Sigma_xx), sqrt(thr Sigma_yy) --
+             * intersected with the square.  Tiles left out cannot contribute (alpha < 1/255 on every pixel), so
+             * colour and gradients are unchanged; the Gaussian stays visible (radii, depth, colour).  ln is bounded
+             * from above with exactly rounded operations only so that the rectangle is reproducible bit for bit. */
+            const float x = 255.0f * a->opacities[i];
+            if (x >= 1.0f) {
+                uint32_t u; memcpy(&u, &x, 4);
+                const int e = (int)(u >> 23) - 127;
+                uint32_t mu = (u & 0x007FFFFFu) | 0x3F800000u;
+                float m; memcpy(&m, &mu, 4);
+                const float lm = (m < 1.5f) ? (m - 1.0f) : (0.405465126f + (m - 1.5f) * 0.666666687f);
+                const float thr = 2.0f * ((float)e * 0.693147182f + lm) + 0.002f;
+                const float hx = fminf(sqrtf(thr * cov[0]), 1.0e7f), hy = fminf(sqrtf(thr * cov[2]), 1.0e7f);
+                int sminx = (int)((px - hx) / BLOCK_X), sminy = (int)((py - hy) / BLOCK_Y);
+                int smaxx = (int)((px + hx) / BLOCK_X) + 1, smaxy = (int)((py + hy) / BLOCK_Y) + 1;
+                if (sminx > minx) minx = sminx;
+                if (sminy > miny) miny = sminy;
+                if (smaxx < maxx) maxx = smaxx;
+                if (smaxy < maxy) maxy = smaxy;
+                if (maxx < minx) maxx = minx;
+                if (maxy < miny) maxy = miny;
+            } else {
+                maxx = minx;
+                maxy = miny;
+            }
+        }
         if (a->colors_precomp) {
             for (int k = 0; k < 3; k++) rgb[3 * i + k] = a->colors_precomp[3 * i + k];
         } else {

@@ -25,7 +25,7 @@ class OrArgs(ctypes.Structure):
         ("cov3D_precomp", c_void_p), ("viewmatrix", c_void_p), ("projmatrix", c_void_p),
         ("campos", c_void_p),
         ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
-        ("prefiltered", c_int),
+        ("prefiltered", c_int), ("tile_rect", c_int),
     ]
 
 
@@ -64,7 +64,7 @@ class Scene(object):
 
     def __init__(self, W, H, tanfovx, tanfovy, bg, viewmatrix, projmatrix, campos, means3D, opacities,
                  shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                 sh_degree=0, scale_modifier=1.0, prefiltered=False):
+                 sh_degree=0, scale_modifier=1.0, prefiltered=False, tile_rect=0):
         self.W, self.H = int(W), int(H)
         self.tanfovx, self.tanfovy = float(tanfovx), float(tanfovy)
         self.bg = _f32(bg).reshape(3)
@@ -83,6 +83,7 @@ class Scene(object):
         self.M = 0 if self.shs is None else int(self.shs.shape[1])
         self.scale_modifier = float(scale_modifier)
         self.prefiltered = bool(prefiltered)
+        self.tile_rect = int(tile_rect)  # 0 = upstream's 3-sigma square, 1 = bounding box of the alpha >= 1/255 region
         if (self.shs is None) == (self.colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((self.scales is None or self.rotations is None) and self.cov3D_precomp is None) or \
@@ -98,6 +99,7 @@ class Scene(object):
         a.viewmatrix, a.projmatrix, a.campos = _ptr(self.viewmatrix), _ptr(self.projmatrix), _ptr(self.campos)
         a.scale_modifier, a.tanfovx, a.tanfovy = self.scale_modifier, self.tanfovx, self.tanfovy
         a.prefiltered = int(self.prefiltered)
+        a.tile_rect = int(self.tile_rect)
         return a
 
 

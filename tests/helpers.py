@@ -18,8 +18,15 @@ def cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=0, dist2_fn=None, heavy
     return cloud, cam
 
 
+def product_tile_rect():
+    """The tile-rectangle mode the product runs with (GsFwdArgs.tile_rect; GSPLAT_TILE_RECT, default 1): the oracle is
+    put in the same mode wherever internal buffers (tiles_touched, lists, ranges) are compared."""
+    import os
+    return int(os.environ.get("GSPLAT_TILE_RECT", "1"))
+
+
 def oracle_scene(cloud, cam, bg=(0.0, 0.0, 0.0), color_mode="sh", cov_mode="scale_rot", scale_modifier=1.0,
-                 colors=None):
+                 colors=None, tile_rect=None):
     """Builds the oracle's Scene from a cloud + camera in one of the four input combinations of the
     rasterizer API."""
     from oracle import gs_oracle
@@ -37,7 +44,8 @@ def oracle_scene(cloud, cam, bg=(0.0, 0.0, 0.0), color_mode="sh", cov_mode="scal
     return gs_oracle.Scene(cam.image_width, cam.image_height, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                            np.asarray(bg, np.float32), cam.world_view_transform.numpy(),
                            cam.full_proj_transform.numpy(), cam.camera_center.numpy(), cloud.xyz.numpy(),
-                           cloud.opacity.numpy(), scale_modifier=scale_modifier, **kw)
+                           cloud.opacity.numpy(), scale_modifier=scale_modifier,
+                           tile_rect=product_tile_rect() if tile_rect is None else tile_rect, **kw)
 
 
 def precomp_colors(cloud, cam):

@@ -292,10 +292,10 @@ def test_heavy_tail_stress_config5_shape(oracle):
     fw = oracle.forward(sc)
     st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
                              shs=cloud.shs.to(dev), cov3D_precomp=helpers.covariance6_cpu(cloud).to(dev))
-    assert st["D"] == fw["binning"]["D"] and st["D"] > 40 * n
+    assert st["D"] == fw["binning"]["D"] and st["D"] > 20 * n
     assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"])
     r = fw["binning"]["ranges"]
-    assert (r[:, 1] - r[:, 0]).max() > 2000  # tiles with long lists
+    assert (r[:, 1] - r[:, 0]).max() > 1000  # tiles with long lists
     _bulk_close(st["color"], fw["color"], name="color")
     gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9))
     want = oracle.backward(sc, fw, gimg.numpy())
@@ -815,3 +815,50 @@ def test_hip_path_against_dense_float64_autograd_directly(oracle, color_mode, co
     for name, ref in grads64.items():
         err = helpers.rel_to_max(got[name].cpu().numpy().reshape(ref.shape), ref)
         assert err < 2e-4, (name, err)
+
+
+@pytest.mark.gpu
+def test_snug_tile_rectangles_give_bitwise_the_same_outputs_as_upstream_squares(oracle):
+    """GsFwdArgs.tile_rect: 1 (default, bounding box of the alpha >= 1/255 region) against 0 (upstream's 3-sigma
+    square) through the product: colour and radii bitwise identical, every gradient equal to fp32 rounding,
+    num_rendered much smaller; and each mode matches the oracle's binning in the same mode bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n, W, H = 6000, 200, 150
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=41, scale_mul=1.4)
+    cloud.opacity[::5] *= 0.05
+    cloud.opacity[::37] = 0.003
+    bg = (0.2, 0.4, 0.6)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    saved = dgr._TILE_RECT
+    res = {}
+    try:
+        for mode in (0, 1):
+            dgr._TILE_RECT = mode
+            kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+            means3D = cloud.xyz.to(dev).requires_grad_(True)
+            means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+            opac = cloud.opacity.to(dev).requires_grad_(True)
+            settings = _settings(cam, cloud, bg, dev)
+            color, radii = dgr.GaussianRasterizer(settings)(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+            (color * gimg).sum().backward()
+            st = debug.forward_state(settings, means3D.detach(), opac.detach(), **{k: v.detach() for k, v in kw.items()})
+            res[mode] = dict(color=color.detach().clone(), radii=radii.clone(), D=st["D"], st=st,
+                             grads=[t.grad.clone() for t in (means3D, means2D, opac, kw["shs"], kw["scales"], kw["rotations"])])
+    finally:
+        dgr._TILE_RECT = saved
+    assert torch.equal(res[0]["color"], res[1]["color"]) and torch.equal(res[0]["radii"], res[1]["radii"])
+    # the gradient rows are the same in both modes; the per-Gaussian reduction adds them in an order that depends on
+    # the pair numbering, so the sums agree to fp32 rounding rather than bit for bit (the oracle, which accumulates in
+    # double, is bitwise identical: tests/test_oracle.py)
+    for a, b in zip(res[0]["grads"], res[1]["grads"]):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+        assert np.array_equal(a == 0, b == 0)
+    assert res[1]["D"] < 0.8 * res[0]["D"]
+    for mode in (0, 1):  # each mode against the oracle in the same mode, bit for bit
+        fw = oracle.forward(helpers.oracle_scene(cloud, cam, bg=bg, tile_rect=mode))
+        assert res[mode]["D"] == fw["binning"]["D"]
+        assert np.array_equal(res[mode]["st"]["geom"]["tiles_touched"], fw["geom"]["tiles_touched"])
+        assert np.array_equal(res[mode]["st"]["binning"]["point_list"], fw["binning"]["point_list"])

@@ -404,3 +404,32 @@ def test_adam_oracle_vs_torch_optim_adam(oracle):
             assert np.allclose(p.detach().numpy(), q, rtol=1e-12, atol=1e-15)
             assert np.allclose(opt.state[p]["exp_avg"].numpy(), m, rtol=1e-12, atol=1e-18)
             assert np.allclose(opt.state[p]["exp_avg_sq"].numpy(), v, rtol=1e-12, atol=1e-18)
+
+
+def test_snug_tile_rectangles_change_no_output(oracle):
+    """GsFwdArgs.tile_rect = 1 (bounding box of the alpha >= 1/255 region instead of upstream's 3-sigma square): in the
+    oracle the rectangle is a subset of the square, far fewer pairs are emitted, and colour, radii, final_T and EVERY
+    gradient are BITWISE those of the square -- the tiles left out contribute exactly nothing."""
+    n, W, H = 6000, 200, 150
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=41, scale_mul=1.4)
+    cloud.opacity[::5] *= 0.05   # low opacities shrink the box further
+    cloud.opacity[::37] = 0.003  # below 1/255: visible (radius > 0) but binned nowhere
+    out = {}
+    for mode in (0, 1):
+        sc = helpers.oracle_scene(cloud, cam, bg=(0.2, 0.4, 0.6), tile_rect=mode)
+        fw = oracle.forward(sc)
+        g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).numpy()
+        out[mode] = (fw, oracle.backward(sc, fw, g))
+    (f0, b0), (f1, b1) = out[0], out[1]
+    r0, r1 = f0["geom"]["rect"], f1["geom"]["rect"]
+    vis = f0["radii"] > 0
+    assert np.array_equal(f0["radii"], f1["radii"])
+    assert (r1[vis, 0] >= r0[vis, 0]).all() and (r1[vis, 1] >= r0[vis, 1]).all()
+    assert (r1[vis, 2] <= r0[vis, 2]).all() and (r1[vis, 3] <= r0[vis, 3]).all()
+    assert f1["binning"]["D"] < 0.8 * f0["binning"]["D"]
+    assert (f1["geom"]["tiles_touched"][(cloud.opacity.numpy().reshape(-1) < 1 / 255) & vis] == 0).all()
+    assert np.array_equal(f0["color"], f1["color"])
+    assert np.array_equal(f0["image"]["final_T"], f1["image"]["final_T"])
+    for k in b0:
+        if b0[k] is not None and isinstance(b0[k], np.ndarray):
+            assert np.array_equal(b0[k], b1[k]), k
