@@ -237,7 +237,7 @@ def main():
                 (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "") +
                 (", + densification statistics + Adam step" if args.train_step else "") +
                 ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
-                "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
+                "tile_rect": int(os.environ.get("GSPLAT_TILE_RECT", "1")), "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
                 "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
                 "broadcast_s": round(t_bcast, 6)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
