@@ -58,8 +58,19 @@ def _bulk_close(got, want, tol=TOL, frac=2e-5, name=""):
 COMBOS = [("sh", "scale_rot", 3), ("precomp", "cov", 3), ("sh", "cov", 1), ("precomp", "scale_rot", 0), ("sh", "scale_rot", 2)]
 
 
+@pytest.fixture(params=[0, 1], ids=["upstream-squares", "alpha-bounding-boxes"])
+def tile_rect(request):
+    """Runs a test in both tile-rectangle modes (GsFwdArgs.tile_rect) of the product; the oracle is put in the same
+    mode through helpers.oracle_scene(..., tile_rect=...)."""
+    import diff_gaussian_rasterization as dgr
+    saved = dgr._TILE_RECT
+    dgr._TILE_RECT = request.param
+    yield request.param
+    dgr._TILE_RECT = saved
+
+
 @pytest.mark.parametrize("color_mode,cov_mode,deg", COMBOS)
-def test_preprocess_and_binning_bit_exact(oracle, color_mode, cov_mode, deg):
+def test_preprocess_and_binning_bit_exact(oracle, tile_rect, color_mode, cov_mode, deg):
     from gsplat_mi355 import debug
     dev = torch.device("cuda:0")
     n, W, H = 3000, 200, 136  # ragged: not a multiple of 16
@@ -68,7 +79,7 @@ def test_preprocess_and_binning_bit_exact(oracle, color_mode, cov_mode, deg):
     cloud.xyz[50:80, 0] *= 3.0  # beyond the 1.3*tanfov clamp
     cloud.shs[:, 0] -= 1.2 * (torch.arange(n) % 5 == 0).float()[:, None]
     bg = (0.1, 0.3, 0.2)
-    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode, tile_rect=tile_rect)
     fw = oracle.forward(sc)
     st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
                              **_inputs(cloud, cam, color_mode, cov_mode, dev))
