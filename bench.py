@@ -257,7 +257,7 @@ def main():
 
 def cpu_baseline(cloud, W, H, deg, gt, do_bwd, threads):
     """The CPU oracle (oracle/gs_oracle.c, kind 'port': the reference has no CPU path and its CUDA
-    source is absent) timed on the host cores on ONE frame of the same workload."""
+    source is absent) timed on the host cores on three frames of the same workload."""
     ncpu = len(os.sched_getaffinity(0))
     nthr = threads if threads > 0 else min(ncpu, 16)
     import helpers
@@ -267,16 +267,24 @@ def cpu_baseline(cloud, W, H, deg, gt, do_bwd, threads):
     gs_oracle.build()
     gs_oracle.set_num_threads(nthr)
     c = GaussianCloud(*[getattr(cloud, f).detach().cpu() for f in GaussianCloud.FIELDS], deg)
-    cam = orbit_camera(0, W, H)
-    sc = helpers.oracle_scene(c, cam)
+    gt_np = gt.cpu().numpy()
+
+    def frame(i):
+        sc = helpers.oracle_scene(c, orbit_camera(i, W, H))
+        fw = gs_oracle.forward(sc)
+        if do_bwd:
+            g = (np.sign(fw["color"] - gt_np) / gt_np.size).astype(np.float32)
+            gs_oracle.backward(sc, fw, g)
+
+    frame(0)  # untimed: first touch of the oracle's buffers
+    nfr = 3
     t0 = time.perf_counter()
-    fw = gs_oracle.forward(sc)
-    if do_bwd:
-        g = (np.sign(fw["color"] - gt.cpu().numpy()) / gt.numel()).astype(np.float32)
-        gs_oracle.backward(sc, fw, g)
+    for i in range(1, 1 + nfr):
+        frame(i)
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": gs_oracle.num_threads(), "kind": "port",
-            "sample": "1 frame (%s) of the same scene, %.1f s of wall time" % ("fwd+bwd" if do_bwd else "fwd", dt)}
+    return {"value": round(nfr / dt, 4), "unit": "frames/s", "cores": gs_oracle.num_threads(), "kind": "port",
+            "sample": "%d frames (%s) of the same scene after one untimed frame, %.1f s of wall time on %d threads" % (
+                nfr, "fwd+bwd" if do_bwd else "fwd", dt, gs_oracle.num_threads())}
 
 
 if __name__ == "__main__":

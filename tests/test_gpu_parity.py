@@ -290,6 +290,54 @@ def test_full_size_properties_config2_50k_512(oracle):
     _bulk_close(st["color"], fw["color"], name="color 50k/512")
 
 
+def test_full_size_config3_200k_1024_forward_backward(oracle):
+    """The bench workload itself (BASELINE config 3: 200k Gaussians, 1024x1024, SH3, forward + backward) against the
+    oracle -- about a second per oracle pass on the box's host cores -- plus two properties that need no oracle: the
+    backward is linear in dL/dimage, and a second run gives the same bits."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsplat_mi355 import debug
+    from simple_knn._C import distCUDA2
+    dev = torch.device("cuda:0")
+    n, W, H = 200000, 1024, 1024
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
+    bg = (0.0, 0.0, 0.0)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg)
+    fw = oracle.forward(sc)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    assert st["D"] == fw["binning"]["D"] and st["D"] > 3000000
+    assert np.array_equal(st["radii"], fw["radii"])
+    assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"])
+    assert np.array_equal(st["image"]["ranges"], fw["binning"]["ranges"])
+    _bulk_close(st["color"], fw["color"], name="color 200k/1024")
+
+    g1 = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
+    g2 = torch.randn(3, H, W, generator=torch.Generator().manual_seed(6))
+    want = oracle.backward(sc, fw, g1.numpy())
+
+    def grads(gimg):
+        leaves = dict(means3D=cloud.xyz.to(dev).requires_grad_(True),
+                      means2D=torch.zeros(n, 3, device=dev, requires_grad=True),
+                      opacities=cloud.opacity.to(dev).requires_grad_(True), shs=cloud.shs.to(dev).requires_grad_(True),
+                      scales=cloud.scales.to(dev).requires_grad_(True),
+                      rotations=cloud.rotations.to(dev).requires_grad_(True))
+        color, _ = GaussianRasterizer(_settings(cam, cloud, bg, dev))(**leaves)
+        (color * gimg.to(dev)).sum().backward()
+        return {k: v.grad.cpu().numpy().astype(np.float64) for k, v in leaves.items()}
+
+    got = grads(g1)
+    names = dict(means3D="means3D", means2D="means2D", opacities="opacities", shs="sh", scales="scales",
+                 rotations="rotations")
+    for k, v in got.items():
+        _bulk_close(v, want[names[k]].reshape(v.shape), tol=2e-5, frac=2e-4, name=k + " 200k/1024")
+    again = grads(g1)
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
+    both, second = grads(g1 + g2), grads(g2)
+    for k in got:
+        _bulk_close(both[k], got[k] + second[k], tol=2e-5, frac=2e-4, name="linearity " + k)
+
+
 def test_heavy_tail_stress_config5_shape(oracle):
     """BASELINE config 5 in miniature: 5 % of the Gaussians with 4x scales (long per-tile lists, many
     64-entry chunks per quadrant), non-zero background, precomputed covariances."""
