@@ -218,18 +218,34 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int 
 // ends with its SIMDs finishing together instead of on the few that drew several centre tiles.
 // mode 0: work = list length (ranges), mode 1: work = sum of keys[4 tile .. 4 tile + 3] (the forward's
 // per-quadrant last contributor).
+__device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
+                                              int t) {
+    return mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
+}
+// HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the inputs are loaded once, all
+// loads in flight together (ntiles <= 32 * 1024); otherwise the three phases re-read them.
+template <bool HELD>
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ keys, int mode, int ntiles,
                                                           uint32_t* __restrict__ order) {
+    constexpr int PER = 32;
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wmax[16];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     hist[tid] = 0;
+    uint32_t held[HELD ? PER : 1];
     uint32_t mx = 0;
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
-        mx = max(mx, w);
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;  // workgroup-uniform
+            const int t = i * 1024 + tid;
+            held[i] = t < ntiles ? tile_work(ranges, keys, mode, t) : 0u;
+            mx = max(mx, held[i]);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
@@ -238,10 +254,15 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     mx = 0;
     for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
     const float scale = mx ? 1023.0f / (float)mx : 0.f;
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
-        const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
-        atomicAdd(&hist[bin], 1u);
+    auto bin_of = [&](uint32_t w) { return 1023u - min(1023u, (uint32_t)((float)w * scale)); };
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            if (i * 1024 + tid < ntiles) atomicAdd(&hist[bin_of(held[i])], 1u);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u);
     }
     __syncthreads();
     // exclusive scan of the 1024 bins
@@ -258,17 +279,27 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     for (int w = 0; w < wid; w++) woff += wsum[w];
     hist[tid] = woff + x - v;
     __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
-        const uint32_t bin = 1023u - min(1023u, (uint32_t)((float)w * scale));
-        order[atomicAdd(&hist[bin], 1u)] = (uint32_t)t;
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            const int t = i * 1024 + tid;
+            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t;
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024)
+            order[atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u)] = (uint32_t)t;
     }
 }
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
                       hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys, mode,
-                       ntiles, order);
+    if (ntiles <= 32 * 1024)
+        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys,
+                           mode, ntiles, order);
+    else
+        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys,
+                           mode, ntiles, order);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }
