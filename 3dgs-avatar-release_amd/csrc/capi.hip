@@ -334,13 +334,9 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
             hipError_t e = hipMemsetAsync(q8, 0xFF, (size_t)D * 16, s);  // ROW_UNWRITTEN everywhere
             if (e != hipSuccess) { gs_set_error((int)e, "q8.memset"); return GS_E_HIP; }
         }
-        static const bool reuse_fwd_order = getenv("GSPLAT_BWD_ORDER_FWD") != nullptr;  // EXPERIMENT
-        if (reuse_fwd_order) order_b = (uint32_t*)(im + I.order);
-        else {
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, a->debug, s); }
         if (rc != GS_OK) return rc;
-        }
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
                                     out_color, dL_dpix, dL_dopacity_img, (const float*)(im + I.final_T), a->bg, (float*)scratch, q8,
