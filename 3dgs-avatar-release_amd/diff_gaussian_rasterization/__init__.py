@@ -178,6 +178,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
             gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if _SHARE else None
+            if gkey is not None:  # the cached state is only valid in stream order: a hit must come from the same stream
+                gkey["scalars"] = gkey["scalars"] + (int(stream.cuda_stream),)
             hit = _geom_cache.lookup(dev, gkey) if _SHARE else None
             if hit is not None:
                 # same geometry and camera as the previous call: new colours only
