@@ -57,7 +57,9 @@ class _GeomCache(object):
 
     def key(self, settings, means3D, opacities, scales, rotations, cov3D):
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
-                             float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT),
+                             float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT,
+                             # the cached state is only valid in stream order: a hit must come from the same stream
+                             int(torch.cuda.current_stream(means3D.device).cuda_stream)),
                     tensors=[self._sig(t) for t in (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix,
                                                     settings.projmatrix, settings.campos)])
 
@@ -178,8 +180,6 @@ class _RasterizeGaussians(torch.autograd.Function):
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
             gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if _SHARE else None
-            if gkey is not None:  # the cached state is only valid in stream order: a hit must come from the same stream
-                gkey["scalars"] = gkey["scalars"] + (int(stream.cuda_stream),)
             hit = _geom_cache.lookup(dev, gkey) if _SHARE else None
             if hit is not None:
                 # same geometry and camera as the previous call: new colours only
