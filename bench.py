@@ -79,12 +79,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = False
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal of the multi-rank code path on a one-GPU box (never for a reported number): all ranks on cuda:0,
+        # gloo instead of RCCL -- GSPLAT_BENCH_REHEARSAL=1
+        rehearsal = os.environ.get("GSPLAT_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -238,7 +247,7 @@ def main():
                 (", + densification statistics + Adam step" if args.train_step else "") +
                 ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
                 "tile_rect": int(os.environ.get("GSPLAT_TILE_RECT", "1")), "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
-                "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world,
+                "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
                 "broadcast_s": round(t_bcast, 6)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
