@@ -921,3 +921,53 @@ def test_snug_tile_rectangles_give_bitwise_the_same_outputs_as_upstream_squares(
         assert res[mode]["D"] == fw["binning"]["D"]
         assert np.array_equal(res[mode]["st"]["geom"]["tiles_touched"], fw["geom"]["tiles_touched"])
         assert np.array_equal(res[mode]["st"]["binning"]["point_list"], fw["binning"]["point_list"])
+
+
+def test_two_host_threads_on_two_streams_render_the_single_stream_bits():
+    """The library keeps no state between calls and works on the caller's stream: frames rendered
+    concurrently from two host threads, each on its own stream, equal the single-stream frames bit for bit
+    (forward and gradients)."""
+    import threading
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 8000, 256, 208
+    cloud, _ = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=21, scale_mul=1.3)
+    from gsplat_mi355.camera import orbit_camera
+    cams = [orbit_camera(f * 5, W, H) for f in range(6)]
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
+    base = {k: getattr(cloud, k).to(dev) for k in ("xyz", "opacity", "shs", "scales", "rotations")}
+
+    def frame(i):
+        leaves = dict(means3D=base["xyz"].clone().requires_grad_(True), means2D=torch.zeros(n, 3, device=dev, requires_grad=True),
+                      opacities=base["opacity"].clone().requires_grad_(True), shs=base["shs"].clone().requires_grad_(True),
+                      scales=base["scales"].clone().requires_grad_(True), rotations=base["rotations"].clone().requires_grad_(True))
+        color, radii = GaussianRasterizer(_settings(cams[i], cloud, (0.1, 0.2, 0.3), dev))(**leaves)
+        (color * gimg).sum().backward()
+        return [color.detach(), radii] + [v.grad for v in leaves.values()]
+
+    want = [frame(i) for i in range(len(cams))]
+    torch.cuda.synchronize()
+    got, errors = {}, []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            st.wait_stream(torch.cuda.default_stream(dev))
+            with torch.cuda.stream(st):
+                for rep in range(3):
+                    for i in range(tid, len(cams), 2):
+                        got[i] = frame(i)
+                st.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for i in range(len(cams)):
+        for a, b in zip(got[i], want[i]):
+            assert torch.equal(a, b), i
