@@ -52,6 +52,7 @@ def build(force=False, verbose=False):
         flags = list(COMMON) + (["-ffp-contract=off"] if src in STRICT else ["-ffp-contract=fast"])
         if src in NO_SLP:
             flags.append("-fno-slp-vectorize")
+        flags += os.environ.get("GSPLAT_EXTRA_HIPCC_FLAGS", "").split()  # experiments (e.g. -DKNN_BOX=64)
         cmd = [cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

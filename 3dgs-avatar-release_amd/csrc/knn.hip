@@ -3,7 +3,7 @@
 // scene/gaussian_model.py:186).
 //
 // Morton-order the points (30-bit code, sorted with this library's radix sort), gather them into
-// a contiguous float4 array, build one AABB per box of 256 consecutive points, then per point scan
+// a contiguous float4 array, build one AABB per box of 64 consecutive points, then per point scan
 // only the boxes whose AABB is not farther than the current third-best distance.  Pruning is exact
 // in fp32: the box distance uses the same subtract / square / add sequence as the point distance, and
 // every step of that sequence is monotone, so fl(box distance) <= fl(point distance) for every
@@ -11,7 +11,7 @@
 #include "common.h"
 #include <float.h>
 
-#define KNN_BOX 256
+#define KNN_BOX 64   // points per box of the Morton-ordered reference set (= one wave of queries)
 #define KNN_WAVE 64  // the search kernels run one wave per workgroup: their barriers and votes are wave-level
 
 struct KnnLayout {
@@ -136,79 +136,40 @@ __global__ __launch_bounds__(KNN_BOX) void knn_box_kernel(int P, const float4* _
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        boxes[blockIdx.x * 8 + c] = fminf(fminf(smin[c][0], smin[c][1]), fminf(smin[c][2], smin[c][3]));
-        boxes[blockIdx.x * 8 + 4 + c] = fmaxf(fmaxf(smax[c][0], smax[c][1]), fmaxf(smax[c][2], smax[c][3]));
+        float a = smin[c][0], b = smax[c][0];
+#pragma unroll
+        for (int w = 1; w < KNN_BOX / 64; w++) { a = fminf(a, smin[c][w]); b = fmaxf(b, smax[c][w]); }
+        boxes[blockIdx.x * 8 + c] = a;
+        boxes[blockIdx.x * 8 + 4 + c] = b;
     }
 }
 
-__device__ __forceinline__ void kbest3(float d, float* best) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (best[k] > d) { const float t = best[k]; best[k] = d; d = t; }
-    }
-}
 __device__ __forceinline__ float dist2(const float4 a, const float4 b) {
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     return dx * dx + dy * dy + dz * dz;
 }
 
-// The points of the box being scanned are staged in LDS by the whole workgroup: its 256 queries are consecutive in Morton order, so they want nearly the same boxes, and a
-// per-thread walk over global memory pays a full memory latency per point (one dependent load per iteration).
-// A box is loaded when ANY query of the group wants it; each query still scans only the boxes it wants itself,
-// so the results are those of the per-thread walk.
-
-__global__ __launch_bounds__(KNN_WAVE) void knn_search_kernel(int P, int nbox, const float4* __restrict__ sp,
-                                                         const float* __restrict__ boxes, float* __restrict__ out) {
-    __shared__ float4 tile[KNN_BOX];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = r < P;
-    const float4 p = active ? sp[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-    // seed the rejection radius from the Morton neighbours
-    if (active)
-        for (int i = max(0, r - 3); i <= min(P - 1, r + 3); i++) {
-            if (i == r) continue;
-            kbest3(dist2(p, sp[i]), best);
-        }
-    const float reject = best[2];
-    best[0] = best[1] = best[2] = FLT_MAX;
-    // boxes are visited outwards from the group's own box (its 256 queries ARE box blockIdx.x), so the K-th best
-    // distance is tight before the far boxes are tested -- most of them then fail the AABB test
-    const int own = (int)(blockIdx.x * KNN_WAVE) / KNN_BOX;  // a wave's 64 queries lie in one box
-    for (int d = 0; own + d < nbox || own - d >= 0; d++) {
-        for (int side = 0; side < 2; side++) {
-            const int b = side == 0 ? own + d : own - d;
-            if ((d == 0 && side == 1) || b < 0 || b >= nbox) continue;  // uniform
-            const float4 lo = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8);  // wave-uniform address
-            const float4 hi = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8 + 4);
-            // gap per axis, written as (point - nearest box point) so it rounds like dist2()
-            const float gx = (p.x < lo.x) ? (p.x - lo.x) : ((p.x > hi.x) ? (p.x - hi.x) : 0.f);
-            const float gy = (p.y < lo.y) ? (p.y - lo.y) : ((p.y > hi.y) ? (p.y - hi.y) : 0.f);
-            const float gz = (p.z < lo.z) ? (p.z - lo.z) : ((p.z > hi.z) ? (p.z - hi.z) : 0.f);
-            const float dbox = gx * gx + gy * gy + gz * gz;
-            const bool want = active && !(dbox > reject || dbox > best[2]);
-            if (!__any(want)) continue;  // wave-uniform
-            __syncthreads();  // (one wave: orders the previous scan before this refill)
-            const int base = b * KNN_BOX, cnt = min(P - base, KNN_BOX);
-            for (int e = threadIdx.x; e < cnt; e += KNN_WAVE) tile[e] = sp[base + e];
-            __syncthreads();
-            if (want)
-                for (int i = 0; i < cnt; i++) {
-                    const float dd = dist2(p, tile[i]);
-                    if (dd < best[2] && base + i != r) kbest3(dd, best);  // (equal to the third best changes nothing)
-                }
-        }
-    }
-    if (active) out[__float_as_uint(p.w)] = (best[0] + best[1] + best[2]) / 3.0f;
-}
-
-// ---- general K nearest neighbours (pytorch3d.ops.knn_points as the reference calls it,
+// ---- the search.  One kernel serves distCUDA2 (K = 3, the point itself excluded, mean of the three squared
+// distances) and knn_points (pytorch3d.ops.knn_points as the reference calls it,
 // utils/loss_utils.py:76-79,92-96 -- K = 5 / 6 self-KNN of the canonical Gaussians every step -- and
-// models/deformer/rigid.py:43 -- nearest SMPL vertex, K = 1).  Same machinery as distCUDA2: the REFERENCE set is
-// Morton-ordered and boxed; every query scans the boxes, skipping those whose AABB is farther than its
-// current K-th best (exact in fp32, see the header).  Results: squared distances ascending, ties broken by the
-// smaller reference index; the query point itself is NOT excluded (a self-KNN returns itself first, as
-// pytorch3d does).
+// models/deformer/rigid.py:43 -- nearest SMPL vertex, K = 1; squared distances ascending, ties broken by the smaller
+// reference index, the query point itself NOT excluded, as pytorch3d).
+//
+// One wave per 64 queries.  For a self-KNN the queries ARE the Morton-ordered points, so a wave's queries are box
+// `blockIdx.x` of the reference set:
+//   0. it scans its own box and the two Morton neighbours of it: every lane then holds a K-th best distance that is
+//      already close to final;
+//   1. boxes are filtered 64 at a time, one box per lane, against the WAVE's query bounding box and the wave's
+//      largest K-th best (a lower bound of every lane's own box distance, see below) -- a few dozen coalesced loads
+//      instead of one dependent load per box and wave (that walk over all boxes was most of the old kernel's time);
+//   2. the survivors get the exact per-query test; a box some lanes still want is loaded one point per lane and
+//      measured against those queries one at a time (scan_box_sparse).
+// Pruning stays exact in fp32.  Per query: the gap to a box is written as (point - nearest box point) per axis so
+// it rounds like dist2(), and every step of subtract / square / add is monotone, so fl(box distance) <=
+// fl(point distance) for every point of the box.  Per wave: the gap between the query bounding box and the box is
+// no larger than any query's own gap on every axis (p <= qhi => lo - p >= lo - qhi, and rounding is monotone), so
+// fl(wave bound) <= fl(query bound); and a lane's K-th best only shrinks, so a box dropped against the wave's
+// largest K-th best now could never be wanted later.
 #define KNN_MAXK 8
 
 // (K is a template parameter everywhere: a run-time K would index the two lists dynamically, which puts them in
@@ -226,15 +187,37 @@ __device__ __forceinline__ void kbest_insert(float d, uint32_t id, float* bd, ui
     }
 }
 
-// sorted_queries: the queries ARE the Morton-ordered reference points (self-KNN; query r = sp[r], answers go to
-// row sp[r].w); otherwise queries[q] is read in the given order.
-template <int K>
-__global__ __launch_bounds__(KNN_WAVE) void knn_points_kernel(int Nq, const float* __restrict__ queries, int sorted_queries,
-                                                         int Nr, int nbox, const float4* __restrict__ sp,
-                                                         const float* __restrict__ boxes,
-                                                         float* __restrict__ out_d, long long* __restrict__ out_i) {
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float lane_value(float v, int src_lane) {  // src_lane wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+// squared gap between the interval [qlo, qhi] (a point when qlo == qhi) and the box [lo, hi], per axis as
+// (query side - box side) so that a point query rounds exactly like dist2()
+__device__ __forceinline__ float axis_gap(float qlo, float qhi, float lo, float hi) {
+    return (qhi < lo) ? (qhi - lo) : ((qlo > hi) ? (qlo - hi) : 0.f);
+}
+
+// sorted_queries: the queries ARE the Morton-ordered reference points (query r = sp[r], answers go to row sp[r].w);
+// otherwise queries[q] is read in the given order.  DIST2: distCUDA2's output (out_d[row] = mean of the K distances,
+// the point itself -- by index, not by position -- left out).
+template <int K, bool DIST2>
+__global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float* __restrict__ queries, int sorted_queries,
+                                                            int Nr, int nbox, const float4* __restrict__ sp,
+                                                            const float* __restrict__ boxes, float* __restrict__ out_d,
+                                                            long long* __restrict__ out_i) {
+    static_assert(KNN_BOX == KNN_WAVE, "a wave of sorted queries is one box");
     __shared__ float4 tile[KNN_BOX];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x * KNN_WAVE + lane;
     const bool active = r < Nq;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t row = 0;
@@ -247,54 +230,126 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_points_kernel(int Nq, const floa
             row = (size_t)r;
         }
     }
+    const uint32_t self_id = (DIST2 && active) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
     float bd[K];
     uint32_t bi[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = 0xFFFFFFFFu; }
-    float reject = FLT_MAX;
-    if (sorted_queries && active) {
-        // seed the rejection radius from the Morton neighbours (they are re-found in the scan below)
-        for (int i = max(0, r - K); i <= min(Nr - 1, r + K); i++) kbest_insert<K>(dist2(p, sp[i]), __float_as_uint(sp[i].w), bd, bi);
-        reject = bd[K - 1];
-#pragma unroll
-        for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = 0xFFFFFFFFu; }
+
+    auto scan_box = [&](int b, bool want) {
+        __syncthreads();  // (one wave: orders the previous scan before this refill)
+        const int base = b * KNN_BOX, cnt = min(Nr - base, KNN_BOX);
+        if (lane < cnt) tile[lane] = sp[base + lane];
+        __syncthreads();
+        if (want)
+            for (int i = 0; i < cnt; i++) {
+                const float4 o = tile[i];
+                const float dd = dist2(p, o);
+                const uint32_t id = __float_as_uint(o.w);
+                // most points are no better than the current K-th best: one compare instead of the K-deep
+                // insertion chain (which a wave only enters when one of its lanes has a candidate)
+                if ((dd < bd[K - 1] || (dd == bd[K - 1] && id < bi[K - 1])) && id != self_id) kbest_insert<K>(dd, id, bd, bi);
+            }
+    };
+
+    // The same for a box only SOME lanes want (every box after step 0): the box's points sit one per lane, and the
+    // wanting queries are taken one at a time -- all 64 lanes measure their point against that query, a ballot
+    // finds the few points that beat its K-th best, and only those enter its list.  Cost per (query, box) pair
+    // instead of per (box, 64 points) whatever the number of lanes that want it.
+    auto scan_box_sparse = [&](int b, unsigned long long wantmask) {
+        const int base = b * KNN_BOX, cnt = min(Nr - base, KNN_BOX);
+        const bool ovalid = lane < cnt;
+        const float4 o = ovalid ? sp[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t oid = __float_as_uint(o.w);
+        while (wantmask) {
+            const int q = __ffsll((long long)wantmask) - 1;
+            wantmask &= wantmask - 1;
+            const float4 pq = make_float4(lane_value(p.x, q), lane_value(p.y, q), lane_value(p.z, q), 0.f);
+            const float kd = lane_value(bd[K - 1], q);
+            const uint32_t kid = (uint32_t)__builtin_amdgcn_readlane((int)bi[K - 1], q);
+            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)self_id, q);
+            const float dd = dist2(pq, o);
+            unsigned long long pm = __ballot(ovalid && (dd < kd || (dd == kd && oid < kid)) && oid != sid);
+            while (pm) {  // (a candidate that an earlier one of this batch pushed out again falls off the list's end)
+                const int j = __ffsll((long long)pm) - 1;
+                pm &= pm - 1;
+                const float cd = lane_value(dd, j);
+                const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)oid, j);
+                if (lane == q) kbest_insert<K>(cd, cid, bd, bi);
+            }
+        }
+    };
+
+    // 0. own box and its Morton neighbours (self-KNN only; -2 = nothing scanned yet)
+    const int own = sorted_queries ? (int)blockIdx.x : -2;
+    if (sorted_queries)
+        for (int b = max(own - 1, 0); b <= min(own + 1, nbox - 1); b++) scan_box(b, active);
+
+    // the wave's query bounding box (inactive lanes neutral)
+    const float BIG = FLT_MAX;
+    const float qlx = wave_min_f(active ? p.x : BIG), qhx = wave_max_f(active ? p.x : -BIG);
+    const float qly = wave_min_f(active ? p.y : BIG), qhy = wave_max_f(active ? p.y : -BIG);
+    const float qlz = wave_min_f(active ? p.z : BIG), qhz = wave_max_f(active ? p.z : -BIG);
+
+    // 1. + 2.  chunks of 64 boxes, outwards from the chunk of the own box; the next chunk's boxes are loaded while
+    // this one's survivors are scanned
+    const int nchunk = (nbox + 63) / 64;
+    const int c0 = sorted_queries ? own / 64 : 0;
+    auto chunk_of = [&](int t) {  // t-th chunk of the walk c0, c0+1, c0-1, c0+2, ... (-1: outside)
+        const int d = (t + 1) >> 1;
+        const int c = (t & 1) ? c0 + d : c0 - d;
+        return (c >= 0 && c < nchunk) ? c : -1;
+    };
+    auto load_chunk = [&](int c, float4& lo, float4& hi) {
+        const int bb = c * 64 + lane;
+        if (c >= 0 && bb < nbox) {
+            lo = *reinterpret_cast<const float4*>(boxes + (size_t)bb * 8);
+            hi = *reinterpret_cast<const float4*>(boxes + (size_t)bb * 8 + 4);
+        }
+    };
+    const int tmax = 2 * max(c0, nchunk - 1 - c0);  // last t that can name a chunk
+    float4 lo = make_float4(0, 0, 0, 0), hi = lo, nlo = lo, nhi = lo;
+    load_chunk(chunk_of(0), lo, hi);
+    for (int t = 0; t <= tmax; t++) {
+        const int c = chunk_of(t);
+        if (t + 1 <= tmax) load_chunk(chunk_of(t + 1), nlo, nhi);
+        if (c >= 0) {
+            const int bb = c * 64 + lane;
+            const float wx = axis_gap(qlx, qhx, lo.x, hi.x), wy = axis_gap(qly, qhy, lo.y, hi.y),
+                        wz = axis_gap(qlz, qhz, lo.z, hi.z);
+            const float wbound = wx * wx + wy * wy + wz * wz;
+            const float rmax = wave_max_f(active ? bd[K - 1] : 0.f);
+            unsigned long long cand = __ballot(bb < nbox && !(wbound > rmax));
+            while (cand) {
+                const int j = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int b = c * 64 + j;
+                if (b >= own - 1 && b <= own + 1) continue;  // scanned in step 0
+                const float lx = lane_value(lo.x, j), ly = lane_value(lo.y, j), lz = lane_value(lo.z, j);
+                const float hx = lane_value(hi.x, j), hy = lane_value(hi.y, j), hz = lane_value(hi.z, j);
+                const float gx = axis_gap(p.x, p.x, lx, hx), gy = axis_gap(p.y, p.y, ly, hy), gz = axis_gap(p.z, p.z, lz, hz);
+                const float dbox = gx * gx + gy * gy + gz * gz;
+                const unsigned long long wantmask = __ballot(active && !(dbox > bd[K - 1]));
+                if (wantmask) scan_box_sparse(b, wantmask);
+            }
+        }
+        lo = nlo;
+        hi = nhi;
     }
-    // self-KNN: the group's 256 queries are box blockIdx.x; visit the boxes outwards from it so the K-th best
-    // distance is tight before the far boxes are tested.  Foreign queries have no such order: from box 0 upwards.
-    const int own = sorted_queries ? (int)(blockIdx.x * KNN_WAVE) / KNN_BOX : 0;  // wave-uniform
-    for (int d = 0; own + d < nbox || own - d >= 0; d++) {
-        for (int side = 0; side < 2; side++) {
-            const int b = side == 0 ? own + d : own - d;
-            if ((d == 0 && side == 1) || b < 0 || b >= nbox) continue;  // uniform
-            const float4 lo = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8);  // wave-uniform address
-            const float4 hi = *reinterpret_cast<const float4*>(boxes + (size_t)b * 8 + 4);
-            const float gx = (p.x < lo.x) ? (p.x - lo.x) : ((p.x > hi.x) ? (p.x - hi.x) : 0.f);
-            const float gy = (p.y < lo.y) ? (p.y - lo.y) : ((p.y > hi.y) ? (p.y - hi.y) : 0.f);
-            const float gz = (p.z < lo.z) ? (p.z - lo.z) : ((p.z > hi.z) ? (p.z - hi.z) : 0.f);
-            const float dbox = gx * gx + gy * gy + gz * gz;
-            const bool want = active && !(dbox > reject || dbox > bd[K - 1]);
-            if (!__any(want)) continue;  // wave-uniform
-            __syncthreads();  // (one wave: orders the previous scan before this refill)
-            const int base = b * KNN_BOX, cnt = min(Nr - base, KNN_BOX);
-            for (int e = threadIdx.x; e < cnt; e += KNN_WAVE) tile[e] = sp[base + e];
-            __syncthreads();
-            if (want)
-                for (int i = 0; i < cnt; i++) {
-                    const float4 o = tile[i];
-                    const float dd = dist2(p, o);
-                    const uint32_t id = __float_as_uint(o.w);
-                    // most points are no better than the current K-th best: one compare instead of the K-deep
-                    // insertion chain (which a wave only enters when one of its lanes has a candidate)
-                    if (dd < bd[K - 1] || (dd == bd[K - 1] && id < bi[K - 1])) kbest_insert<K>(dd, id, bd, bi);
-                }
+    if (active) {
+        if (DIST2) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; k++) sum += bd[k];
+            out_d[row] = sum / (float)K;
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                out_d[row * K + k] = bd[k];
+                out_i[row * K + k] = (bi[k] == 0xFFFFFFFFu) ? -1ll : (long long)bi[k];  // fewer than K reference points: -1
+            }
         }
     }
-    if (active)
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            out_d[row * K + k] = bd[k];
-            out_i[row * K + k] = (bi[k] == 0xFFFFFFFFu) ? -1ll : (long long)bi[k];  // fewer than K reference points: -1
-        }
 }
 
 int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, int K, float* out_d, long long* out_i,
@@ -324,8 +379,8 @@ int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, in
     const int self = (queries == ref && Nq == Nr) ? 1 : 0;
 #define KNN_LAUNCH(KK)                                                                                                   \
     case KK:                                                                                                             \
-        hipLaunchKernelGGL(knn_points_kernel<KK>, dim3((Nq + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, Nq, queries, self, Nr, L.nbox, sp, \
-                           boxes, out_d, out_i);                                                                         \
+        hipLaunchKernelGGL((knn_scan_kernel<KK, false>), dim3((Nq + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, Nq, queries, \
+                           self, Nr, L.nbox, sp, boxes, out_d, out_i);                                                   \
         break;
     switch (K) {
         KNN_LAUNCH(1) KNN_LAUNCH(2) KNN_LAUNCH(3) KNN_LAUNCH(4) KNN_LAUNCH(5) KNN_LAUNCH(6) KNN_LAUNCH(7) KNN_LAUNCH(8)
@@ -358,7 +413,8 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp);
     hipLaunchKernelGGL(knn_box_kernel, dim3(L.nbox), dim3(KNN_BOX), 0, s, P, sp, boxes);
-    hipLaunchKernelGGL(knn_search_kernel, dim3((P + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, P, L.nbox, sp, boxes, out);
+    hipLaunchKernelGGL((knn_scan_kernel<3, true>), dim3((P + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, P,
+                       (const float*)nullptr, 1, P, L.nbox, sp, boxes, out, (long long*)nullptr);
     GS_LAUNCH_CHECK("knn.search", 0, s);
     return GS_OK;
 }
