@@ -2,7 +2,7 @@
 // nearest OTHER points (exact).  Replaces simple_knn's simple_knn.cu (un-vendored; call site
 // scene/gaussian_model.py:186).
 //
-// Morton-order the points (30-bit code, sorted with this library's radix sort), gather them into
+// Morton-order the points (24-bit code, sorted with this library's radix sort), gather them into
 // a contiguous float4 array, build one AABB per box of 64 consecutive points, then per point scan
 // only the boxes whose AABB is not farther than the current third-best distance.  Pruning is exact
 // in fp32: the box distance uses the same subtract / square / add sequence as the point distance, and
@@ -13,6 +13,7 @@
 
 #define KNN_BOX 64   // points per box of the Morton-ordered reference set (= one wave of queries)
 #define KNN_WAVE 64  // the search kernels run one wave per workgroup: their barriers and votes are wave-level
+#define KNN_MM_BLOCKS 128  // blocks of the bounding-box pass; each leaves its own partial (no atomics, nothing to clear)
 
 struct KnnLayout {
     size_t key0, key1, val0, val1, hist, pts, boxes, minmax, total;
@@ -32,27 +33,14 @@ static KnnLayout knn_layout(int P) {
     L.hist = take(sort_table_words(n) * 4);
     L.pts = take(n * 16);
     L.boxes = take((size_t)L.nbox * 32);
-    L.minmax = take(64);
+    L.minmax = take((size_t)KNN_MM_BLOCKS * 6 * 4);
     L.total = o;
     return L;
 }
 size_t knn_ws_bytes(int P) { return knn_layout(P).total; }
 
-// order-preserving float <-> uint map for atomicMin / atomicMax
-__device__ __forceinline__ uint32_t f2ord(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t u) {
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
-}
-
-__global__ void knn_init_kernel(uint32_t* mm) {
-    if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu;       // min
-    else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;           // max
-}
-
-__global__ __launch_bounds__(256) void knn_minmax_kernel(int P, const float* __restrict__ pts, uint32_t* mm) {
+// partial bounding boxes: mm[6 b .. 6 b + 5] = (min xyz, max xyz) of block b's grid-stride share
+__global__ __launch_bounds__(256) void knn_minmax_kernel(int P, const float* __restrict__ pts, float* __restrict__ mm) {
     __shared__ float smin[3][4], smax[3][4];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
@@ -75,72 +63,89 @@ __global__ __launch_bounds__(256) void knn_minmax_kernel(int P, const float* __r
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        const float a = fminf(fminf(smin[c][0], smin[c][1]), fminf(smin[c][2], smin[c][3]));
-        const float b = fmaxf(fmaxf(smax[c][0], smax[c][1]), fmaxf(smax[c][2], smax[c][3]));
-        atomicMin(&mm[c], f2ord(a));
-        atomicMax(&mm[3 + c], f2ord(b));
+        mm[6 * blockIdx.x + c] = fminf(fminf(smin[c][0], smin[c][1]), fminf(smin[c][2], smin[c][3]));
+        mm[6 * blockIdx.x + 3 + c] = fmaxf(fmaxf(smax[c][0], smax[c][1]), fmaxf(smax[c][2], smax[c][3]));
     }
 }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t x) {
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
+// 8 bits -> every third bit
+__device__ __forceinline__ uint32_t spread8(uint32_t x) {
+    x = (x | (x << 8)) & 0x0000F00Fu;
+    x = (x | (x << 4)) & 0x000C30C3u;
+    x = (x | (x << 2)) & 0x00249249u;
     return x;
 }
+#define KNN_MORTON_BITS 24  // 8 per axis: three radix passes; the order only decides how well the boxes prune
 
 __global__ __launch_bounds__(256) void knn_morton_kernel(int P, const float* __restrict__ pts,
-                                                         const uint32_t* __restrict__ mm, uint32_t* __restrict__ keys,
-                                                         uint32_t* __restrict__ vals) {
+                                                         const float* __restrict__ mm, int nparts,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ float sred[6][4];
+    __shared__ float sbox[6];
+    {
+        // every block folds the partial bounding boxes itself (nparts <= KNN_MM_BLOCKS <= 256)
+        const int t = threadIdx.x;
+        float v[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] = (c < 3) ? FLT_MAX : -FLT_MAX;
+        if (t < nparts)
+#pragma unroll
+            for (int c = 0; c < 6; c++) v[c] = mm[6 * t + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float o = __shfl_xor(v[c], d, 64);
+                v[c] = (c < 3) ? fminf(v[c], o) : fmaxf(v[c], o);
+            }
+            if ((t & 63) == 0) sred[c][t >> 6] = v[c];
+        }
+        __syncthreads();
+        if (t < 6)
+            sbox[t] = (t < 3) ? fminf(fminf(sred[t][0], sred[t][1]), fminf(sred[t][2], sred[t][3]))
+                              : fmaxf(fmaxf(sred[t][0], sred[t][1]), fmaxf(sred[t][2], sred[t][3]));
+        __syncthreads();
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     uint32_t code = 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float lo = ord2f(mm[c]), hi = ord2f(mm[3 + c]);
+        const float lo = sbox[c], hi = sbox[3 + c];
         const float ext = fmaxf(hi - lo, 1e-30f);
-        float u = (pts[3 * i + c] - lo) / ext * 1023.0f;
-        u = fminf(fmaxf(u, 0.f), 1023.f);
-        code |= spread10((uint32_t)u) << c;
+        float u = (pts[3 * i + c] - lo) / ext * 255.0f;
+        u = fminf(fmaxf(u, 0.f), 255.f);
+        code |= spread8((uint32_t)u) << c;
     }
     keys[i] = code;
     vals[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void knn_gather_kernel(int P, const float* __restrict__ pts,
-                                                         const uint32_t* __restrict__ order, float4* __restrict__ out) {
+// gather the points into Morton order (xyz + original index) and leave one AABB per box of KNN_BOX = 64 consecutive
+// points: a workgroup of 256 threads is four boxes, one per wave
+__global__ __launch_bounds__(256) void knn_gather_box_kernel(int P, const float* __restrict__ pts,
+                                                             const uint32_t* __restrict__ order, float4* __restrict__ out,
+                                                             float* __restrict__ boxes) {
+    static_assert(KNN_BOX == 64, "one box per wave");
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t i = order[r];
-    out[r] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float(i));
-}
-
-__global__ __launch_bounds__(KNN_BOX) void knn_box_kernel(int P, const float4* __restrict__ sp, float* __restrict__ boxes) {
-    __shared__ float smin[3][4], smax[3][4];
-    const int r = blockIdx.x * KNN_BOX + threadIdx.x;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     if (r < P) {
-        const float4 p = sp[r];
+        const uint32_t i = order[r];
+        const float4 p = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float(i));
+        out[r] = p;
         mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 3; c++)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             mn[c] = fminf(mn[c], __shfl_xor(mn[c], d, 64));
             mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], d, 64));
         }
-        if ((threadIdx.x & 63) == 0) { smin[c][threadIdx.x >> 6] = mn[c]; smax[c][threadIdx.x >> 6] = mx[c]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        float a = smin[c][0], b = smax[c][0];
-#pragma unroll
-        for (int w = 1; w < KNN_BOX / 64; w++) { a = fminf(a, smin[c][w]); b = fmaxf(b, smax[c][w]); }
-        boxes[blockIdx.x * 8 + c] = a;
-        boxes[blockIdx.x * 8 + 4 + c] = b;
+    const int box = r >> 6;
+    if ((threadIdx.x & 63) == 0 && box * KNN_BOX < P) {
+        *reinterpret_cast<float4*>(boxes + (size_t)box * 8) = make_float4(mn[0], mn[1], mn[2], 0.f);
+        *reinterpret_cast<float4*>(boxes + (size_t)box * 8 + 4) = make_float4(mx[0], mx[1], mx[2], 0.f);
     }
 }
 
@@ -256,11 +261,15 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
     // wanting queries are taken one at a time -- all 64 lanes measure their point against that query, a ballot
     // finds the few points that beat its K-th best, and only those enter its list.  Cost per (query, box) pair
     // instead of per (box, 64 points) whatever the number of lanes that want it.
-    auto scan_box_sparse = [&](int b, unsigned long long wantmask) {
-        const int base = b * KNN_BOX, cnt = min(Nr - base, KNN_BOX);
-        const bool ovalid = lane < cnt;
-        const float4 o = ovalid ? sp[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_box = [&](int b, float4& o, bool& ovalid) {
+        const int base = b * KNN_BOX;
+        ovalid = base + lane < Nr;
+        o = ovalid ? sp[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto scan_box_sparse = [&](const float4 o, const bool ovalid, unsigned long long wantmask) {
         const uint32_t oid = __float_as_uint(o.w);
+        // which points of the box beat which query's K-th best: a 64-bit mask per query, parked in that query's lane
+        uint32_t mlo = 0u, mhi = 0u;
         while (wantmask) {
             const int q = __ffsll((long long)wantmask) - 1;
             wantmask &= wantmask - 1;
@@ -269,14 +278,21 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
             const uint32_t kid = (uint32_t)__builtin_amdgcn_readlane((int)bi[K - 1], q);
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)self_id, q);
             const float dd = dist2(pq, o);
-            unsigned long long pm = __ballot(ovalid && (dd < kd || (dd == kd && oid < kid)) && oid != sid);
-            while (pm) {  // (a candidate that an earlier one of this batch pushed out again falls off the list's end)
-                const int j = __ffsll((long long)pm) - 1;
-                pm &= pm - 1;
-                const float cd = lane_value(dd, j);
-                const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)oid, j);
-                if (lane == q) kbest_insert<K>(cd, cid, bd, bi);
+            const unsigned long long pm = __ballot(ovalid && (dd < kd || (dd == kd && oid < kid)) && oid != sid);
+            if (pm) {
+                if (lane == q) { mlo = (uint32_t)pm; mhi = (uint32_t)(pm >> 32); }
             }
+        }
+        // ... and all queries insert their candidates together, one candidate each per trip (the insertion chain is
+        // K deep: run once per candidate under a one-lane mask it cost more than the search itself)
+        unsigned long long mine = ((unsigned long long)mhi << 32) | mlo;
+        while (__any(mine != 0ull)) {
+            const bool has = mine != 0ull;
+            const int j = has ? __ffsll((long long)mine) - 1 : 0;
+            mine &= mine - 1;  // (0 stays 0)
+            const float4 c = make_float4(__shfl(o.x, j, 64), __shfl(o.y, j, 64), __shfl(o.z, j, 64), 0.f);
+            const uint32_t cid = (uint32_t)__shfl((int)oid, j, 64);
+            if (has) kbest_insert<K>(dist2(p, c), cid, bd, bi);  // (the same subtraction, so the same bits as above)
         }
     };
 
@@ -309,6 +325,9 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
     };
     const int tmax = 2 * max(c0, nchunk - 1 - c0);  // last t that can name a chunk
     float4 lo = make_float4(0, 0, 0, 0), hi = lo, nlo = lo, nhi = lo;
+    float4 po = lo;  // the wanted box whose points are in flight
+    bool pov = false, have = false;
+    unsigned long long pmask = 0ull;
     load_chunk(chunk_of(0), lo, hi);
     for (int t = 0; t <= tmax; t++) {
         const int c = chunk_of(t);
@@ -330,12 +349,22 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
                 const float gx = axis_gap(p.x, p.x, lx, hx), gy = axis_gap(p.y, p.y, ly, hy), gz = axis_gap(p.z, p.z, lz, hz);
                 const float dbox = gx * gx + gy * gy + gz * gz;
                 const unsigned long long wantmask = __ballot(active && !(dbox > bd[K - 1]));
-                if (wantmask) scan_box_sparse(b, wantmask);
+                if (wantmask) {
+                    // the box's points are requested now and measured when the NEXT wanted box has been found, so a
+                    // memory latency is never waited for with nothing else in flight (the mask is from now: a
+                    // superset of what would be wanted then)
+                    float4 o;
+                    bool ov;
+                    load_box(b, o, ov);
+                    if (have) scan_box_sparse(po, pov, pmask);
+                    po = o; pov = ov; pmask = wantmask; have = true;
+                }
             }
         }
         lo = nlo;
         hi = nhi;
     }
+    if (have) scan_box_sparse(po, pov, pmask);
     if (active) {
         if (DIST2) {
             float sum = 0.f;
@@ -364,18 +393,17 @@ int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, in
     uint32_t* hist = (uint32_t*)(w + L.hist);
     float4* sp = (float4*)(w + L.pts);
     float* boxes = (float*)(w + L.boxes);
-    uint32_t* mm = (uint32_t*)(w + L.minmax);
+    float* mm = (float*)(w + L.minmax);
     const int nb = (Nr + 255) / 256;
     StageScope st("knn_points", s);
-    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(64), 0, s, mm);
-    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, Nr, ref, mm);
-    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, mm, k0, v0);
+    const int nparts = nb < KNN_MM_BLOCKS ? nb : KNN_MM_BLOCKS;
+    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, Nr, ref, mm);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, mm, nparts, k0, v0);
     GS_LAUNCH_CHECK("knn.morton", 0, s);
-    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, Nr, 30, false, 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, Nr, KNN_MORTON_BITS, false, 0, s);
     if (rc != GS_OK) return rc;
-    const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
-    hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, order, sp);
-    hipLaunchKernelGGL(knn_box_kernel, dim3(L.nbox), dim3(KNN_BOX), 0, s, Nr, sp, boxes);
+    const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
+    hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, order, sp, boxes);
     const int self = (queries == ref && Nq == Nr) ? 1 : 0;
 #define KNN_LAUNCH(KK)                                                                                                   \
     case KK:                                                                                                             \
@@ -402,17 +430,16 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     uint32_t* hist = (uint32_t*)(w + L.hist);
     float4* sp = (float4*)(w + L.pts);
     float* boxes = (float*)(w + L.boxes);
-    uint32_t* mm = (uint32_t*)(w + L.minmax);
+    float* mm = (float*)(w + L.minmax);
     const int nb = (P + 255) / 256;
-    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(64), 0, s, mm);
-    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, P, points, mm);
-    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, mm, k0, v0);
+    const int nparts = nb < KNN_MM_BLOCKS ? nb : KNN_MM_BLOCKS;
+    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, P, points, mm);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, mm, nparts, k0, v0);
     GS_LAUNCH_CHECK("knn.morton", 0, s);
-    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, 30, false, 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, KNN_MORTON_BITS, false, 0, s);
     if (rc != GS_OK) return rc;
-    const uint32_t* order = (radix_passes(30) & 1) ? v1 : v0;
-    hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp);
-    hipLaunchKernelGGL(knn_box_kernel, dim3(L.nbox), dim3(KNN_BOX), 0, s, P, sp, boxes);
+    const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
+    hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp, boxes);
     hipLaunchKernelGGL((knn_scan_kernel<3, true>), dim3((P + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, P,
                        (const float*)nullptr, 1, P, L.nbox, sp, boxes, out, (long long*)nullptr);
     GS_LAUNCH_CHECK("knn.search", 0, s);
