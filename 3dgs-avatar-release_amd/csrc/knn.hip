@@ -162,8 +162,8 @@ __device__ __forceinline__ float dist2(const float4 a, const float4 b) {
 //
 // One wave per 64 queries.  For a self-KNN the queries ARE the Morton-ordered points, so a wave's queries are box
 // `blockIdx.x` of the reference set:
-//   0. it scans its own box and the two Morton neighbours of it: every lane then holds a K-th best distance that is
-//      already close to final;
+//   0. it scans its own box (and for K >= 3 the two Morton neighbours), all lanes inserting in parallel: every lane
+//      then holds a K-th best distance that is already close to final;
 //   1. boxes are filtered 64 at a time, one box per lane, against the WAVE's query bounding box and the wave's
 //      largest K-th best (a lower bound of every lane's own box distance, see below) -- a few dozen coalesced loads
 //      instead of one dependent load per box and wave (that walk over all boxes was most of the old kernel's time);
@@ -179,15 +179,21 @@ __device__ __forceinline__ float dist2(const float4 a, const float4 b) {
 
 // (K is a template parameter everywhere: a run-time K would index the two lists dynamically, which puts them in
 // scratch memory -- measured 30x slower)
+// A list entry is one 64-bit key, (squared distance bits << 32) | reference index: squared distances are >= +0, whose
+// bit patterns order like the floats, so ONE unsigned 64-bit compare is "nearer, or as near with the smaller index".
+typedef unsigned long long knn_key;
+__device__ __forceinline__ knn_key make_key(float d, uint32_t id) { return ((knn_key)__float_as_uint(d) << 32) | id; }
+__device__ __forceinline__ float key_dist(knn_key k) { return __uint_as_float((uint32_t)(k >> 32)); }
+#define KNN_EMPTY_KEY (((knn_key)0x7F7FFFFFu << 32) | 0xFFFFFFFFu)  // (FLT_MAX, no index)
+
 template <int K>
-__device__ __forceinline__ void kbest_insert(float d, uint32_t id, float* bd, uint32_t* bi) {
+__device__ __forceinline__ void kbest_insert(knn_key c, knn_key* key) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if (bd[k] > d || (bd[k] == d && bi[k] > id)) {
-            const float td = bd[k];
-            const uint32_t ti = bi[k];
-            bd[k] = d; bi[k] = id;
-            d = td; id = ti;
+        if (key[k] > c) {
+            const knn_key t = key[k];
+            key[k] = c;
+            c = t;
         }
     }
 }
@@ -236,10 +242,9 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
         }
     }
     const uint32_t self_id = (DIST2 && active) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
-    float bd[K];
-    uint32_t bi[K];
+    knn_key key[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = 0xFFFFFFFFu; }
+    for (int k = 0; k < K; k++) key[k] = KNN_EMPTY_KEY;
 
     auto scan_box = [&](int b, bool want) {
         __syncthreads();  // (one wave: orders the previous scan before this refill)
@@ -249,11 +254,11 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
         if (want)
             for (int i = 0; i < cnt; i++) {
                 const float4 o = tile[i];
-                const float dd = dist2(p, o);
                 const uint32_t id = __float_as_uint(o.w);
+                const knn_key c = make_key(dist2(p, o), id);
                 // most points are no better than the current K-th best: one compare instead of the K-deep
                 // insertion chain (which a wave only enters when one of its lanes has a candidate)
-                if ((dd < bd[K - 1] || (dd == bd[K - 1] && id < bi[K - 1])) && id != self_id) kbest_insert<K>(dd, id, bd, bi);
+                if (c < key[K - 1] && id != self_id) kbest_insert<K>(c, key);
             }
     };
 
@@ -274,11 +279,10 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
             const int q = __ffsll((long long)wantmask) - 1;
             wantmask &= wantmask - 1;
             const float4 pq = make_float4(lane_value(p.x, q), lane_value(p.y, q), lane_value(p.z, q), 0.f);
-            const float kd = lane_value(bd[K - 1], q);
-            const uint32_t kid = (uint32_t)__builtin_amdgcn_readlane((int)bi[K - 1], q);
+            const knn_key kq = ((knn_key)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[K - 1] >> 32), q) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[K - 1], q);
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)self_id, q);
-            const float dd = dist2(pq, o);
-            const unsigned long long pm = __ballot(ovalid && (dd < kd || (dd == kd && oid < kid)) && oid != sid);
+            const unsigned long long pm = __ballot(ovalid && make_key(dist2(pq, o), oid) < kq && oid != sid);
             if (pm) {
                 if (lane == q) { mlo = (uint32_t)pm; mhi = (uint32_t)(pm >> 32); }
             }
@@ -292,14 +296,15 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
             mine &= mine - 1;  // (0 stays 0)
             const float4 c = make_float4(__shfl(o.x, j, 64), __shfl(o.y, j, 64), __shfl(o.z, j, 64), 0.f);
             const uint32_t cid = (uint32_t)__shfl((int)oid, j, 64);
-            if (has) kbest_insert<K>(dist2(p, c), cid, bd, bi);  // (the same subtraction, so the same bits as above)
+            if (has) kbest_insert<K>(make_key(dist2(p, c), cid), key);  // (the same subtraction, so the same bits as above)
         }
     };
 
-    // 0. own box and its Morton neighbours (self-KNN only; -2 = nothing scanned yet)
+    // 0. own box (self-KNN only; -2 = nothing scanned yet)
     const int own = sorted_queries ? (int)blockIdx.x : -2;
+    const int nb0 = K >= 3 ? 1 : 0;  // for K >= 3 the two Morton neighbours too: measured faster (tighter bounds for step 1)
     if (sorted_queries)
-        for (int b = max(own - 1, 0); b <= min(own + 1, nbox - 1); b++) scan_box(b, active);
+        for (int b = max(own - nb0, 0); b <= min(own + nb0, nbox - 1); b++) scan_box(b, active);
 
     // the wave's query bounding box (inactive lanes neutral)
     const float BIG = FLT_MAX;
@@ -337,18 +342,18 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
             const float wx = axis_gap(qlx, qhx, lo.x, hi.x), wy = axis_gap(qly, qhy, lo.y, hi.y),
                         wz = axis_gap(qlz, qhz, lo.z, hi.z);
             const float wbound = wx * wx + wy * wy + wz * wz;
-            const float rmax = wave_max_f(active ? bd[K - 1] : 0.f);
+            const float rmax = wave_max_f(active ? key_dist(key[K - 1]) : 0.f);
             unsigned long long cand = __ballot(bb < nbox && !(wbound > rmax));
             while (cand) {
                 const int j = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
                 const int b = c * 64 + j;
-                if (b >= own - 1 && b <= own + 1) continue;  // scanned in step 0
+                if (b >= own - nb0 && b <= own + nb0) continue;  // scanned in step 0
                 const float lx = lane_value(lo.x, j), ly = lane_value(lo.y, j), lz = lane_value(lo.z, j);
                 const float hx = lane_value(hi.x, j), hy = lane_value(hi.y, j), hz = lane_value(hi.z, j);
                 const float gx = axis_gap(p.x, p.x, lx, hx), gy = axis_gap(p.y, p.y, ly, hy), gz = axis_gap(p.z, p.z, lz, hz);
                 const float dbox = gx * gx + gy * gy + gz * gz;
-                const unsigned long long wantmask = __ballot(active && !(dbox > bd[K - 1]));
+                const unsigned long long wantmask = __ballot(active && !(dbox > key_dist(key[K - 1])));
                 if (wantmask) {
                     // the box's points are requested now and measured when the NEXT wanted box has been found, so a
                     // memory latency is never waited for with nothing else in flight (the mask is from now: a
@@ -369,13 +374,14 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
         if (DIST2) {
             float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; k++) sum += bd[k];
+            for (int k = 0; k < K; k++) sum += key_dist(key[k]);
             out_d[row] = sum / (float)K;
         } else {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                out_d[row * K + k] = bd[k];
-                out_i[row * K + k] = (bi[k] == 0xFFFFFFFFu) ? -1ll : (long long)bi[k];  // fewer than K reference points: -1
+                const uint32_t id = (uint32_t)key[k];
+                out_d[row * K + k] = key_dist(key[k]);
+                out_i[row * K + k] = (id == 0xFFFFFFFFu) ? -1ll : (long long)id;  // fewer than K reference points: -1
             }
         }
     }
