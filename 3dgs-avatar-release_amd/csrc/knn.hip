@@ -40,8 +40,11 @@ static KnnLayout knn_layout(int P) {
 size_t knn_ws_bytes(int P) { return knn_layout(P).total; }
 
 // partial bounding boxes: mm[6 b .. 6 b + 5] = (min xyz, max xyz) of block b's grid-stride share
-__global__ __launch_bounds__(256) void knn_minmax_kernel(int P, const float* __restrict__ pts, float* __restrict__ mm) {
+// (also clears the radix sort's digit totals on the side: a fill launch less)
+__global__ __launch_bounds__(256) void knn_minmax_kernel(int P, const float* __restrict__ pts, float* __restrict__ mm,
+                                                         const ZeroJob zt) {
     __shared__ float smin[3][4], smax[3][4];
+    zero_job(zt);
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
 #pragma unroll
@@ -403,10 +406,12 @@ int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, in
     const int nb = (Nr + 255) / 256;
     StageScope st("knn_points", s);
     const int nparts = nb < KNN_MM_BLOCKS ? nb : KNN_MM_BLOCKS;
-    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, Nr, ref, mm);
+    ZeroJob zt;
+    sort_totals_region(hist, Nr, KNN_MORTON_BITS, &zt.ptr, &zt.words);
+    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, Nr, ref, mm, zt);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, mm, nparts, k0, v0);
     GS_LAUNCH_CHECK("knn.morton", 0, s);
-    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, Nr, KNN_MORTON_BITS, false, 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, Nr, KNN_MORTON_BITS, true, 0, s);
     if (rc != GS_OK) return rc;
     const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, order, sp, boxes);
@@ -439,10 +444,12 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     float* mm = (float*)(w + L.minmax);
     const int nb = (P + 255) / 256;
     const int nparts = nb < KNN_MM_BLOCKS ? nb : KNN_MM_BLOCKS;
-    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, P, points, mm);
+    ZeroJob zt;
+    sort_totals_region(hist, P, KNN_MORTON_BITS, &zt.ptr, &zt.words);
+    hipLaunchKernelGGL(knn_minmax_kernel, dim3(nparts), dim3(256), 0, s, P, points, mm, zt);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, mm, nparts, k0, v0);
     GS_LAUNCH_CHECK("knn.morton", 0, s);
-    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, KNN_MORTON_BITS, false, 0, s);
+    int rc = launch_sort_pairs(k0, v0, k1, v1, hist, P, KNN_MORTON_BITS, true, 0, s);
     if (rc != GS_OK) return rc;
     const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp, boxes);
