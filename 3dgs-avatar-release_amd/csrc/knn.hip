@@ -223,16 +223,18 @@ __device__ __forceinline__ float axis_gap(float qlo, float qhi, float lo, float 
 // sorted_queries: the queries ARE the Morton-ordered reference points (query r = sp[r], answers go to row sp[r].w);
 // otherwise queries[q] is read in the given order.  DIST2: distCUDA2's output (out_d[row] = mean of the K distances,
 // the point itself -- by index, not by position -- left out).
-template <int K, bool DIST2>
+// QPW: queries per wave (16 / 32 / 64; the other lanes only carry box points).  A wave's run time is a long chain of
+// dependent steps, so a small problem is finished sooner by more, shorter waves: the launcher picks QPW from Nq.
+template <int K, bool DIST2, int QPW>
 __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float* __restrict__ queries, int sorted_queries,
                                                             int Nr, int nbox, const float4* __restrict__ sp,
                                                             const float* __restrict__ boxes, float* __restrict__ out_d,
                                                             long long* __restrict__ out_i) {
-    static_assert(KNN_BOX == KNN_WAVE, "a wave of sorted queries is one box");
+    static_assert(KNN_BOX == KNN_WAVE && KNN_BOX % QPW == 0, "a wave's sorted queries lie in one box");
     __shared__ float4 tile[KNN_BOX];
     const int lane = threadIdx.x;
-    const int r = blockIdx.x * KNN_WAVE + lane;
-    const bool active = r < Nq;
+    const int r = blockIdx.x * QPW + lane;
+    const bool active = lane < QPW && r < Nq;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t row = 0;
     if (active) {
@@ -278,17 +280,25 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
         const uint32_t oid = __float_as_uint(o.w);
         // which points of the box beat which query's K-th best: a 64-bit mask per query, parked in that query's lane
         uint32_t mlo = 0u, mhi = 0u;
-        while (wantmask) {
-            const int q = __ffsll((long long)wantmask) - 1;
-            wantmask &= wantmask - 1;
+        auto beat_mask = [&](int q) {  // the points of the box that beat query q's K-th best
             const float4 pq = make_float4(lane_value(p.x, q), lane_value(p.y, q), lane_value(p.z, q), 0.f);
             const knn_key kq = ((knn_key)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[K - 1] >> 32), q) << 32) |
                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[K - 1], q);
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)self_id, q);
-            const unsigned long long pm = __ballot(ovalid && make_key(dist2(pq, o), oid) < kq && oid != sid);
-            if (pm) {
-                if (lane == q) { mlo = (uint32_t)pm; mhi = (uint32_t)(pm >> 32); }
-            }
+            return __ballot(ovalid && make_key(dist2(pq, o), oid) < kq && oid != sid);
+        };
+        while (wantmask) {
+            // two queries per trip: their chains (read lanes -> distance -> compare -> ballot) are independent, and a
+            // lone wave otherwise waits out every step of one chain
+            const int q0 = __ffsll((long long)wantmask) - 1;
+            wantmask &= wantmask - 1;
+            const bool two = wantmask != 0ull;
+            const int q1 = two ? __ffsll((long long)wantmask) - 1 : q0;
+            wantmask &= wantmask - 1;  // (0 stays 0)
+            const unsigned long long pm0 = beat_mask(q0);
+            const unsigned long long pm1 = beat_mask(q1);
+            if (pm0 && lane == q0) { mlo = (uint32_t)pm0; mhi = (uint32_t)(pm0 >> 32); }
+            if (two && pm1 && lane == q1) { mlo = (uint32_t)pm1; mhi = (uint32_t)(pm1 >> 32); }
         }
         // ... and all queries insert their candidates together, one candidate each per trip (the insertion chain is
         // K deep: run once per candidate under a one-lane mask it cost more than the search itself)
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(KNN_WAVE) void knn_scan_kernel(int Nq, const float*
     };
 
     // 0. own box (self-KNN only; -2 = nothing scanned yet)
-    const int own = sorted_queries ? (int)blockIdx.x : -2;
+    const int own = sorted_queries ? (int)(blockIdx.x * QPW) / KNN_BOX : -2;
     const int nb0 = K >= 3 ? 1 : 0;  // for K >= 3 the two Morton neighbours too: measured faster (tighter bounds for step 1)
     if (sorted_queries)
         for (int b = max(own - nb0, 0); b <= min(own + nb0, nbox - 1); b++) scan_box(b, active);
@@ -416,15 +426,22 @@ int launch_knn_points(int Nq, const float* queries, int Nr, const float* ref, in
     const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, Nr, ref, order, sp, boxes);
     const int self = (queries == ref && Nq == Nr) ? 1 : 0;
+    // queries per wave: enough waves to give every SIMD a few (1024 SIMDs)
+    const int qpw = Nq >= (1 << 18) ? 64 : (Nq >= (1 << 17) ? 32 : 16);
+#define KNN_LAUNCH_Q(KK, QQ)                                                                                             \
+    hipLaunchKernelGGL((knn_scan_kernel<KK, false, QQ>), dim3((Nq + QQ - 1) / QQ), dim3(KNN_WAVE), 0, s, Nq, queries, self, \
+                       Nr, L.nbox, sp, boxes, out_d, out_i)
 #define KNN_LAUNCH(KK)                                                                                                   \
     case KK:                                                                                                             \
-        hipLaunchKernelGGL((knn_scan_kernel<KK, false>), dim3((Nq + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, Nq, queries, \
-                           self, Nr, L.nbox, sp, boxes, out_d, out_i);                                                   \
+        if (qpw == 64) KNN_LAUNCH_Q(KK, 64);                                                                             \
+        else if (qpw == 32) KNN_LAUNCH_Q(KK, 32);                                                                        \
+        else KNN_LAUNCH_Q(KK, 16);                                                                                       \
         break;
     switch (K) {
         KNN_LAUNCH(1) KNN_LAUNCH(2) KNN_LAUNCH(3) KNN_LAUNCH(4) KNN_LAUNCH(5) KNN_LAUNCH(6) KNN_LAUNCH(7) KNN_LAUNCH(8)
         default: return GS_E_BAD_ARG;
     }
+#undef KNN_LAUNCH_Q
 #undef KNN_LAUNCH
     GS_LAUNCH_CHECK("knn.points", 0, s);
     return GS_OK;
@@ -453,8 +470,15 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     if (rc != GS_OK) return rc;
     const uint32_t* order = (radix_passes(KNN_MORTON_BITS) & 1) ? v1 : v0;
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nb), dim3(256), 0, s, P, points, order, sp, boxes);
-    hipLaunchKernelGGL((knn_scan_kernel<3, true>), dim3((P + KNN_WAVE - 1) / KNN_WAVE), dim3(KNN_WAVE), 0, s, P,
-                       (const float*)nullptr, 1, P, L.nbox, sp, boxes, out, (long long*)nullptr);
+    if (P >= (1 << 18))
+        hipLaunchKernelGGL((knn_scan_kernel<3, true, 64>), dim3((P + 63) / 64), dim3(KNN_WAVE), 0, s, P, (const float*)nullptr, 1,
+                           P, L.nbox, sp, boxes, out, (long long*)nullptr);
+    else if (P >= (1 << 17))
+        hipLaunchKernelGGL((knn_scan_kernel<3, true, 32>), dim3((P + 31) / 32), dim3(KNN_WAVE), 0, s, P, (const float*)nullptr, 1,
+                           P, L.nbox, sp, boxes, out, (long long*)nullptr);
+    else
+        hipLaunchKernelGGL((knn_scan_kernel<3, true, 16>), dim3((P + 15) / 16), dim3(KNN_WAVE), 0, s, P, (const float*)nullptr, 1,
+                           P, L.nbox, sp, boxes, out, (long long*)nullptr);
     GS_LAUNCH_CHECK("knn.search", 0, s);
     return GS_OK;
 }
