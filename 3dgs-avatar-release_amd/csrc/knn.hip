@@ -11,7 +11,7 @@
 #include "common.h"
 #include <float.h>
 
-#define KNN_BOX 64   // points per box of the Morton-ordered reference set (= one wave of queries)
+#define KNN_BOX 64   // points per box of the Morton-ordered reference set (one point per lane of the search's wave)
 #define KNN_WAVE 64  // the search kernels run one wave per workgroup: their barriers and votes are wave-level
 #define KNN_MM_BLOCKS 128  // blocks of the bounding-box pass; each leaves its own partial (no atomics, nothing to clear)
 
