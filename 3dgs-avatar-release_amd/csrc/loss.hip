@@ -130,68 +130,102 @@ __global__ __launch_bounds__(SS_NT) void ssim_fwd_kernel(int H, int W, const flo
                                                          const float* __restrict__ img2, SsimWindow win,
                                                          float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1,
                                                          float* __restrict__ dm_ds12, float* __restrict__ partial) {
-    __shared__ float t1[SS_H][SS_H + 1], t2[SS_H][SS_H + 1];
+    // the halo tiles live in the front of hx: every thread has its inputs in registers before the first hx word is
+    // written (28 KB per workgroup instead of 42: one more workgroup per CU to hide the tile loads behind)
     __shared__ float hx[5][SS_H][SS_T + 1];
+    float (*t1)[SS_H + 1] = reinterpret_cast<float (*)[SS_H + 1]>(&hx[0][0][0]);
+    float (*t2)[SS_H + 1] = reinterpret_cast<float (*)[SS_H + 1]>(&hx[0][0][0] + SS_H * (SS_H + 1));
+    static_assert(2 * SS_H * (SS_H + 1) <= 5 * SS_H * (SS_T + 1), "halo tiles fit in hx");
     __shared__ float ws[SS_NT / 64];
-    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;  // ty in 0..7: rows ty, ty + 8, ty + 16, ty + 24
+    const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;  // ty in 0..7: rows 4 ty .. 4 ty + 3
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < SS_H * SS_H; e += SS_NT) {
-        const int r = e / SS_H, c = e - r * SS_H;
-        const int y = y0 + r - SS_R, x = x0 + c - SS_R;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
-        t1[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
-        t2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
-    }
-    __syncthreads();
-    // horizontal pass: 42 rows x 32 columns, five moments
-    for (int e = tid; e < SS_H * SS_T; e += SS_NT) {
-        const int r = e / SS_T, c = e - r * SS_T;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float a = t1[r][c + k], b = t2[r][c + k], w = win.w[k];
-            m1 += w * a;
-            m2 += w * b;
-            e11 += w * (a * a);
-            e22 += w * (b * b);
-            e12 += w * (a * b);
+    // halo tiles: 42 rows of 42, a row per trip of 64 threads (no integer division)
+    for (int r = tid >> 6; r < SS_H; r += SS_NT / 64) {
+        const int c = tid & 63;
+        if (c < SS_H) {
+            const int y = y0 + r - SS_R, x = x0 + c - SS_R;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
+            t1[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
+            t2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
         }
-        hx[0][r][c] = m1; hx[1][r][c] = m2; hx[2][r][c] = e11; hx[3][r][c] = e22; hx[4][r][c] = e12;
     }
     __syncthreads();
+    // horizontal pass, 42 rows x 32 columns, five moments: a thread takes 8 adjacent columns of one row and slides the
+    // window over the 18 inputs it holds in registers (one LDS read per input instead of one per tap)
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 8;
+        float a[18], b[18], aa[18], bb[18], ab[18];
+        if (r < SS_H) {
+#pragma unroll
+            for (int j = 0; j < 18; j++) {
+                a[j] = t1[r][c0 + j];
+                b[j] = t2[r][c0 + j];
+                aa[j] = a[j] * a[j];
+                bb[j] = b[j] * b[j];
+                ab[j] = a[j] * b[j];
+            }
+        }
+        __syncthreads();  // the tiles are in registers: hx may overwrite them
+        if (r < SS_H) {
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const float w = win.w[k];
+                    m1 += w * a[o + k];
+                    m2 += w * b[o + k];
+                    e11 += w * aa[o + k];
+                    e22 += w * bb[o + k];
+                    e12 += w * ab[o + k];
+                }
+                hx[0][r][c0 + o] = m1; hx[1][r][c0 + o] = m2; hx[2][r][c0 + o] = e11; hx[3][r][c0 + o] = e22;
+                hx[4][r][c0 + o] = e12;
+            }
+        }
+    }
+    __syncthreads();
+    // vertical pass: a thread takes 4 adjacent rows of one column (14 inputs per moment in registers)
     float val = 0.f;
+    {
+        const int oy0 = ty * 4;  // ty = tid / 32 in 0..7
+        float acc[5][4];
 #pragma unroll
-    for (int q = 0; q < SS_T * SS_T / SS_NT; q++) {
-        const int oy = ty + q * (SS_NT / SS_T);
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        for (int m = 0; m < 5; m++) {
+            float v[14];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            mu1 += w * hx[0][oy + k][tx];
-            mu2 += w * hx[1][oy + k][tx];
-            e11 += w * hx[2][oy + k][tx];
-            e22 += w * hx[3][oy + k][tx];
-            e12 += w * hx[4][oy + k][tx];
+            for (int j = 0; j < 14; j++) v[j] = hx[m][oy0 + j][tx];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) sum += win.w[k] * v[o + k];
+                acc[m][o] = sum;
+            }
         }
-        const int x = x0 + tx, y = y0 + oy;
-        if (x < W && y < H) {
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-            const float A = 2.f * mu12 + SS_C1, B = 2.f * s12 + SS_C2;
-            const float C = mu1_sq + mu2_sq + SS_C1, D = s1 + s2 + SS_C2;
-            const float inv_cd = 1.0f / (C * D);
-            const float v = A * B * inv_cd;
-            val += v;
-            if (dm_dmu1) {
-                // ssim as a function of (mu1, E[x^2], E[xy]) of this window; s1 and s12 depend on mu1 too
-                const float d_s1 = -v / D;              // d ssim / d s1   = -A B / (C D^2)
-                const float d_s12 = 2.f * A * inv_cd;   // d ssim / d s12  =  2 A / (C D)
-                const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * v / C - 2.f * mu1 * d_s1 - mu2 * d_s12;
-                const size_t o = plane + (size_t)y * W + x;
-                dm_dmu1[o] = d_mu1;
-                dm_ds1[o] = d_s1;
-                dm_ds12[o] = d_s12;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
+            const int x = x0 + tx, y = y0 + oy0 + o;
+            if (x < W && y < H) {
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+                const float A = 2.f * mu12 + SS_C1, B = 2.f * s12 + SS_C2;
+                const float C = mu1_sq + mu2_sq + SS_C1, D = s1 + s2 + SS_C2;
+                const float inv_cd = 1.0f / (C * D);
+                const float v = A * B * inv_cd;
+                val += v;
+                if (dm_dmu1) {
+                    // ssim as a function of (mu1, E[x^2], E[xy]) of this window; s1 and s12 depend on mu1 too
+                    const float d_s1 = -v / D;              // d ssim / d s1   = -A B / (C D^2)
+                    const float d_s12 = 2.f * A * inv_cd;   // d ssim / d s12  =  2 A / (C D)
+                    const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * v / C - 2.f * mu1 * d_s1 - mu2 * d_s12;
+                    const size_t oo = plane + (size_t)y * W + x;
+                    dm_dmu1[oo] = d_mu1;
+                    dm_ds1[oo] = d_s1;
+                    dm_ds12[oo] = d_s12;
+                }
             }
         }
     }
@@ -223,50 +257,74 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, const flo
                                                          const float* __restrict__ dm_ds12,
                                                          const float* __restrict__ dL_dssim, float inv_n,
                                                          float* __restrict__ dL_dimg1) {
+    // (hx overwrites the front of t once every thread holds its inputs in registers: 22 KB per workgroup, not 38)
     __shared__ float t[3][SS_H][SS_H + 1];
-    __shared__ float hx[3][SS_H][SS_T + 1];
+    float (*hx)[SS_H][SS_T + 1] = reinterpret_cast<float (*)[SS_H][SS_T + 1]>(&t[0][0][0]);
+    static_assert(SS_T + 1 <= SS_H + 1, "hx fits in t");
     const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < SS_H * SS_H; e += SS_NT) {
-        const int r = e / SS_H, c = e - r * SS_H;
-        const int y = y0 + r - SS_R, x = x0 + c - SS_R;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
-        const size_t o = plane + (size_t)y * W + x;
-        t[0][r][c] = in ? dm_dmu1[o] : 0.f;
-        t[1][r][c] = in ? dm_ds1[o] : 0.f;
-        t[2][r][c] = in ? dm_ds12[o] : 0.f;
+    for (int r = tid >> 6; r < SS_H; r += SS_NT / 64) {
+        const int c = tid & 63;
+        if (c < SS_H) {
+            const int y = y0 + r - SS_R, x = x0 + c - SS_R;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
+            const size_t o = plane + (size_t)y * W + x;
+            t[0][r][c] = in ? dm_dmu1[o] : 0.f;
+            t[1][r][c] = in ? dm_ds1[o] : 0.f;
+            t[2][r][c] = in ? dm_ds12[o] : 0.f;
+        }
     }
     __syncthreads();
-    for (int e = tid; e < SS_H * SS_T; e += SS_NT) {
-        const int r = e / SS_T, c = e - r * SS_T;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    {
+        // horizontal pass: 8 adjacent columns of one row per thread, the 18 inputs of each map in registers
+        const int r = tid >> 2, c0 = (tid & 3) * 8;
+        float v[3][18];
+        if (r < SS_H) {
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            a0 += w * t[0][r][c + k];
-            a1 += w * t[1][r][c + k];
-            a2 += w * t[2][r][c + k];
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int j = 0; j < 18; j++) v[m][j] = t[m][r][c0 + j];
         }
-        hx[0][r][c] = a0; hx[1][r][c] = a1; hx[2][r][c] = a2;
+        __syncthreads();  // the maps are in registers: hx may overwrite them
+        if (r < SS_H) {
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) sum += win.w[k] * v[m][o + k];
+                    hx[m][r][c0 + o] = sum;
+                }
+        }
     }
     __syncthreads();
     const float g = dL_dssim[0] * inv_n;
+    {
+        // vertical pass: 4 adjacent rows of one column per thread
+        const int oy0 = ty * 4;
+        float f[3][4];
 #pragma unroll
-    for (int q = 0; q < SS_T * SS_T / SS_NT; q++) {
-        const int oy = ty + q * (SS_NT / SS_T);
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        for (int m = 0; m < 3; m++) {
+            float v[14];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            f0 += w * hx[0][oy + k][tx];
-            f1 += w * hx[1][oy + k][tx];
-            f2 += w * hx[2][oy + k][tx];
+            for (int j = 0; j < 14; j++) v[j] = hx[m][oy0 + j][tx];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) sum += win.w[k] * v[o + k];
+                f[m][o] = sum;
+            }
         }
-        const int x = x0 + tx, y = y0 + oy;
-        if (x < W && y < H) {
-            const size_t o = plane + (size_t)y * W + x;
-            dL_dimg1[o] = g * (f0 + 2.f * img1[o] * f1 + img2[o] * f2);
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int x = x0 + tx, y = y0 + oy0 + o;
+            if (x < W && y < H) {
+                const size_t oo = plane + (size_t)y * W + x;
+                dL_dimg1[oo] = g * (f[0][o] + 2.f * img1[oo] * f[1][o] + img2[oo] * f[2][o]);
+            }
         }
     }
 }
