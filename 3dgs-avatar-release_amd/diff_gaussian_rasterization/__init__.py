@@ -9,6 +9,7 @@ gaussian_renderer/__init__.py:85-98,121-129): `GaussianRasterizationSettings`, `
 the C ABI of include/gsplat_mi355.h; there is no CPU or PyTorch fallback.
 """
 import ctypes
+import os
 import threading
 from typing import NamedTuple
 
@@ -34,8 +35,6 @@ class GaussianRasterizationSettings(NamedTuple):
     prefiltered: bool
     debug: bool
 
-
-import os
 
 _tls = threading.local()
 _SHARE = os.environ.get("GSPLAT_SHARE_GEOMETRY", "1") != "0"
