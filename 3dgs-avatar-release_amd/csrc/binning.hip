@@ -227,7 +227,13 @@ __device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, 
 template <bool HELD>
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ keys, int mode, int ntiles,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, const FillJob fill) {
+    if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
+        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
+            fill.ptr[k] = ones;
+        return;
+    }
     constexpr int PER = 32;
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wmax[16];
@@ -292,14 +298,17 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     }
 }
 
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
-                      hipStream_t s) {
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, FillJob fill,
+                      int debug, hipStream_t s) {
+    // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
+    const size_t pieces = (fill.quads + 1023) / 1024;
+    const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
-        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys,
-                           mode, ntiles, order);
+        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
+                           keys, mode, ntiles, order, fill);
     else
-        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges), keys,
-                           mode, ntiles, order);
+        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
+                           keys, mode, ntiles, order, fill);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }

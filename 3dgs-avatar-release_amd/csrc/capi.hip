@@ -183,7 +183,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
     }
     { StageScope sc_("tile_order", s);
-    rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), a->debug, s); }
+    rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), FillJob{nullptr, 0}, a->debug, s); }
     if (rc != GS_OK) return rc;
     QuadLists ql;
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
@@ -330,12 +330,10 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
-        {
-            hipError_t e = hipMemsetAsync(q8, 0xFF, (size_t)D * 16, s);  // ROW_UNWRITTEN everywhere
-            if (e != hipSuccess) { gs_set_error((int)e, "q8.memset"); return GS_E_HIP; }
-        }
+        // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, a->debug, s); }
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b,
+                               FillJob{reinterpret_cast<uint4*>(q8), (size_t)D}, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,

@@ -194,8 +194,11 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
                          const float* dm_ds1, const float* dm_ds12, const float* dL_dssim, float* dL_dimg1,
                          hipStream_t s);
 
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, int debug,
-                      hipStream_t s);
+// `fill`: 16-byte words the kernel's other workgroups set to all-ones while the first one orders the tiles (the
+// backward's ROW_UNWRITTEN marks: a fill launch less, and it overlaps the single-workgroup ordering)
+struct FillJob { uint4* ptr; size_t quads; };
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, FillJob fill,
+                      int debug, hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
