@@ -61,7 +61,10 @@ static int validate(const GsFwdArgs* a) {
     if (a->shs) {
         if (a->sh_degree < 0 || a->sh_degree > 3) return GS_E_BAD_ARG;
         if (a->M < (a->sh_degree + 1) * (a->sh_degree + 1)) return GS_E_BAD_ARG;
+        if (a->M > 16) return GS_E_BAD_ARG;  // degree <= 3: the per-Gaussian backward stages 3 M floats per thread in LDS
     }
+    // quaternions are read (and their gradients written) as float4
+    if (a->rotations && ((uintptr_t)a->rotations & 15u)) return GS_E_BAD_ARG;
     if ((a->W + TILE - 1) / TILE > 0xFFFF || (a->H + TILE - 1) / TILE > 0xFFFF) return GS_E_TOO_LARGE;
     return GS_OK;
 }
@@ -311,6 +314,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         return GS_E_BAD_ARG;
     if (a->P > 0 && a->shs && !gr->dL_dsh) return GS_E_BAD_ARG;
     if (a->P > 0 && a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return GS_E_BAD_ARG;
+    if (gr->dL_drotations && ((uintptr_t)gr->dL_drotations & 15u)) return GS_E_BAD_ARG;  // written as float4
     const GeomLayout L = geom_layout(a->P);
     const ImgLayout I = img_layout(a->W, a->H);
     const BinLayout B = bin_layout(D);
@@ -566,7 +570,7 @@ int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches
 const char* gs_status_string(int code) {
     switch (code) {
         case GS_OK: return "ok";
-        case GS_E_BAD_ARG: return "bad argument (null required pointer, non-positive size or unsupported SH degree)";
+        case GS_E_BAD_ARG: return "bad argument (null required pointer, non-positive size, unsupported SH degree / more than 16 SH coefficients, or rotations not 16-byte aligned)";
         case GS_E_EXCLUSIVE: return "provide exactly one of shs/colors_precomp and exactly one of (scales, rotations)/cov3D_precomp";
         case GS_E_TOO_LARGE: return "num_rendered or tile grid exceeds the supported index space";
         case GS_E_HIP: return "HIP error";

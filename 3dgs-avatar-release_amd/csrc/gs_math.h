@@ -98,13 +98,28 @@ __device__ __forceinline__ float ln_upper_bound(float x) {
 }
 
 // Half-widths of the axis-aligned bounding box of { alpha >= 1/255 } = { d^T Sigma^-1 d <= 2 ln(255 opacity) } for
-// the 2-D covariance (a, b, c): sqrt(thr a), sqrt(thr c).  Returns false when alpha stays below 1/255 everywhere.
-__device__ __forceinline__ bool snug_half_widths(float opacity, float cov_a, float cov_c, float* hx, float* hy) {
+// the 2-D covariance (a, b, c) with determinant det: sqrt(thr a), sqrt(thr c).  Returns false when alpha stays below
+// 1/255 everywhere.
+// The per-pixel test is evaluated with the ROUNDED fp32 conic (c/det, -b/det, a/det) and a handful of rounded
+// products, and for a long thin Gaussian det = a c - b^2 is a difference of nearly equal numbers: the quadratic form
+// the pixels see is off by a relative ~2^-24 (a c / det) per rounding, i.e. its level set { <= thr } is the exact
+// ellipse scaled by up to sqrt(1 + k 2^-24 a c / det).  The threshold is widened by that factor (k = 32: conic
+// entries, log2 scaling, the five operations of the power, with room to spare): 1 + 2e-6 for round Gaussians, tens of
+// percent for needles hundreds of pixels long; when a c / det is so large that the bound says nothing (or det <= 0)
+// the half-widths are unbounded and the caller's 3-sigma square stands.
+__device__ __forceinline__ bool snug_half_widths(float opacity, float cov_a, float cov_c, float det, float* hx, float* hy) {
     const float x = 255.0f * opacity;
     if (!(x >= 1.0f)) return false;
     const float thr = 2.0f * ln_upper_bound(x) + 0.002f;  // + margin for the rounding of the per-pixel test
-    *hx = fminf(sqrtf(thr * cov_a), 1.0e7f);
-    *hy = fminf(sqrtf(thr * cov_c), 1.0e7f);
+    const float cond = (cov_a * cov_c) / det;              // >= 1 for a positive definite covariance
+    const float widen = 1.0f + cond * 1.9073486e-6f;       // 32 * 2^-24
+    if (!(det > 0.0f) || !(widen <= 2.0f)) {
+        *hx = *hy = 1.0e7f;
+        return true;
+    }
+    const float thr_w = thr * widen;
+    *hx = fminf(sqrtf(thr_w * cov_a), 1.0e7f);
+    *hy = fminf(sqrtf(thr_w * cov_c), 1.0e7f);
     return true;
 }
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     // bin into the bounding box of the alpha >= 1/255 region only (GsFwdArgs.tile_rect = 1); the
                     // Gaussian stays "visible" (radii, colour, depth) exactly as with the square
                     float hx, hy;
-                    if (snug_half_widths(opacities[i], cov[0], cov[2], &hx, &hy)) {
+                    if (snug_half_widths(opacities[i], cov[0], cov[2], det, &hx, &hy)) {
                         minx = max(minx, (int)((px - hx) / TILE));
                         miny = max(miny, (int)((py - hy) / TILE));
                         maxx = min(maxx, (int)((px + hx) / TILE) + 1);

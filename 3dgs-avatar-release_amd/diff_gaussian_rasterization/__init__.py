@@ -11,6 +11,7 @@ the C ABI of include/gsplat_mi355.h; there is no CPU or PyTorch fallback.
 import ctypes
 import os
 import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -40,48 +41,83 @@ _tls = threading.local()
 _SHARE = os.environ.get("GSPLAT_SHARE_GEOMETRY", "1") != "0"
 
 
+class _GeomEntry(object):
+    """Geometry state of ONE forward call (preprocess, sorts, binning), offered to the call that follows it."""
+    __slots__ = ("key", "geom", "binning", "img", "num_rendered", "radii", "__weakref__")
+
+    def __init__(self, key, geom, binning, img, num_rendered, radii):
+        self.key, self.geom, self.binning, self.img, self.num_rendered, self.radii = key, geom, binning, img, num_rendered, radii
+
+    def release(self):
+        self.key = self.geom = self.binning = self.img = self.radii = None
+
+
 class _GeomCache(object):
-    """State of the most recent forward per device, kept so that an immediately following call with
-    the SAME geometry tensors and camera but different colours (the reference's opacity pass,
-    gaussian_renderer/__init__.py:131-142) can skip preprocess, sorts and binning.
-    Matching is by storage address + autograd version counter (shared by every view of a storage);
-    the cache holds the tensors, so their storage cannot be freed and recycled under it."""
+    """The reference rasterizes twice per step with identical geometry: the colour pass and, right behind it, an
+    opacity pass with colours = 1 (gaussian_renderer/__init__.py:121-142).  The second call can skip preprocess,
+    sorts and binning.  Sharing is restricted to exactly that pattern:
+
+    * a hit needs the SAME tensor objects (identity, plus storage address, shape, strides and autograd version
+      counter) for means3D / opacities / scales / rotations / cov3D and the camera tensors, equal scalar settings,
+      the same device and stream;
+    * only the call IMMEDIATELY after the one that produced the state can hit, and only once: any other forward on
+      the device replaces or drops the offer;
+    * the offer dies when the producing call's backward starts, or when its autograd graph is freed.  The cache
+      itself holds only a weak reference; the state is owned by the producing call's autograd node, so nothing is
+      retained beyond what upstream's ctx retains, and nothing at all without a graph (no_grad inference renders
+      every call in full).
+
+    A parameter update between two renders therefore never meets stale geometry: the optimiser step comes after
+    the backward (which kills the offer), and the library's own raw in-place writers (FusedAdam, densify_stats)
+    also bump the version counters of what they write."""
 
     def __init__(self):
-        self.entry = {}
+        self.offer = {}  # device index -> weakref to the _GeomEntry on offer
+        self.hits = 0    # calls served from a previous call's geometry (diagnostics / tests)
 
     @staticmethod
     def _sig(t):
-        return None if t is None else (t, t.data_ptr(), t._version, t.numel())
+        if t is None or t.numel() == 0:
+            return None
+        return (id(t), t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
     def key(self, settings, means3D, opacities, scales, rotations, cov3D):
+        tensors = (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix, settings.projmatrix, settings.campos)
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
                              float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT,
                              # the cached state is only valid in stream order: a hit must come from the same stream
                              int(torch.cuda.current_stream(means3D.device).cuda_stream)),
-                    tensors=[self._sig(t) for t in (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix,
-                                                    settings.projmatrix, settings.campos)])
+                    sigs=[self._sig(t) for t in tensors],
+                    # the objects themselves: an id() can only be trusted while its object is alive
+                    objs=[t for t in tensors if t is not None and t.numel() > 0])
 
-    @staticmethod
-    def same(a, b):
-        if a["scalars"] != b["scalars"]:
-            return False
-        for x, y in zip(a["tensors"], b["tensors"]):
-            if (x is None) != (y is None):
-                return False
-            if x is not None and x[1:] != y[1:]:
-                return False
-        return True
+    def take(self, dev, key):
+        """The offer for this device if it matches `key` (consumed either way: single use)."""
+        ref = self.offer.pop(dev.index, None)
+        e = ref() if ref is not None else None
+        if e is None or e.key is None:
+            return None
+        if e.key["scalars"] != key["scalars"] or e.key["sigs"] != key["sigs"]:
+            return None
+        self.hits += 1
+        return e
 
-    def lookup(self, dev, key):
-        e = self.entry.get(dev.index)
-        return e if e is not None and self.same(e["key"], key) else None
+    def put(self, dev, entry):
+        self.offer[dev.index] = weakref.ref(entry)
 
-    def store(self, dev, key, **state):
-        self.entry[dev.index] = dict(key=key, **state)
+    def clear(self):
+        self.offer.clear()
 
 
 _geom_cache = _GeomCache()
+
+
+def release_shared_geometry():
+    """Withdraws any geometry state on offer to a following call (it is otherwise withdrawn by the next forward, by the
+    producing call's backward, or when its autograd graph is freed)."""
+    _geom_cache.clear()
+
+
 _last_count = {}  # (device, P, W, H) -> num_rendered of the previous call: a sizing hint only
 
 
@@ -178,18 +214,29 @@ class _RasterizeGaussians(torch.autograd.Function):
             geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
-            gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if _SHARE else None
-            hit = _geom_cache.lookup(dev, gkey) if _SHARE else None
+            # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
+            share = _SHARE and any(ctx.needs_input_grad)  # (true only under grad mode)
+            gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if share else None
+            hit = _geom_cache.take(dev, gkey) if share else None
+            if not share:
+                _geom_cache.offer.pop(dev.index, None)
+            ctx.geom_entry = None
             if hit is not None:
-                # same geometry and camera as the previous call: new colours only
-                num_rendered = hit["num_rendered"]
-                binning = hit["binning"]
+                # same geometry and camera as the call just before: new colours only
+                num_rendered = hit.num_rendered
+                binning = hit.binning
                 bin_bytes = binning.numel()
-                radii.copy_(hit["radii"])
+                radii.copy_(hit.radii)
                 color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-                _lib.check(L.gs_forward_shared(ctypes.byref(a), hit["geom"].data_ptr(), hit["img"].data_ptr(),
+                check_qlist = binning.clone() if (raster_settings.debug and bin_bytes) else None
+                _lib.check(L.gs_forward_shared(ctypes.byref(a), hit.geom.data_ptr(), hit.img.data_ptr(),
                                                geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes, img.data_ptr(),
                                                img_bytes, num_rendered, color.data_ptr(), sptr))
+                if check_qlist is not None and not torch.equal(check_qlist, binning):
+                    # the shared binning state belongs to the first call's autograd node as well: the second forward
+                    # re-records the quadrant lists, which must come out identical for identical geometry
+                    raise RuntimeError("diff_gaussian_rasterization: the shared-geometry render changed the binning "
+                                       "state it shares with the previous call")
                 return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
                                                    img, color, dev, a, sptr)
@@ -216,8 +263,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             if binning is None:  # nothing visible on the first call for this shape
                 binning = torch.empty(0, dtype=torch.uint8, device=dev)
                 bin_bytes = 0
-            if _SHARE:
-                _geom_cache.store(dev, gkey, geom=geom, binning=binning, img=img, num_rendered=num_rendered, radii=radii)
+            if share:
+                # offered to the next call; owned by this call's autograd node (ctx), not by the cache
+                ctx.geom_entry = _GeomEntry(gkey, geom, binning, img, num_rendered, radii)
+                _geom_cache.put(dev, ctx.geom_entry)
             return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,
                                                scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color, dev, a,
                                                sptr)
@@ -246,6 +295,10 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
         L = _lib.load()
+        entry = getattr(ctx, "geom_entry", None)
+        if entry is not None:  # a render after this backward (e.g. after an optimiser step) must not meet this state
+            entry.release()
+            ctx.geom_entry = None
         (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
          color) = ctx.saved_tensors
         has_sh, has_col, has_sr, has_cov = ctx.present

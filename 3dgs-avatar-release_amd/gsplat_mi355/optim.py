@@ -33,6 +33,15 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom)
         sptr = ctypes.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)
         _lib.check(L.gs_densify_stats(n, _lib.ptr(radii), _lib.ptr(viewspace_grad), _lib.ptr(max_radii2D),
                                       _lib.ptr(xyz_gradient_accum), _lib.ptr(denom), sptr))
+    _bump_versions(max_radii2D, xyz_gradient_accum, denom)
+
+
+def _bump_versions(*tensors):
+    """The HIP kernels write through raw pointers, which torch cannot see: bump the autograd version counters as any
+    in-place torch op would, so that whatever keys on them (saved-tensor checks, the rasterizer's shared-geometry
+    matching) sees the write."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -82,4 +91,6 @@ class FusedAdam(torch.optim.Optimizer):
                 with torch.cuda.device(dev):
                     sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                     _lib.check(L.gs_adam_step(len(chunk), arr, b1, b2, eps, step, sptr))
+                for p, _g, m, v, _lr in chunk:
+                    _bump_versions(p, m, v)
         return loss

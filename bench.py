@@ -8,16 +8,31 @@ rasterizer backward.  All inputs are resident in HBM before the timed region.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: frames of an orbit sequence are sharded over the ranks (rank r renders frames r, r+N, ...);
-the Gaussian state is built on rank 0 and sent with ONE RCCL broadcast before the timed region; no
-data-path collective per step.  Weak scaling: every rank renders K frames.
-Rank 0 prints one JSON line.
+N > 1: frames of an orbit sequence are sharded over the ranks (rank r renders frames r, r+N, ...), the
+reference's independent frame loop (render.py:51-62); the Gaussian state is built on rank 0 and sent with ONE
+RCCL broadcast before the timed region; no data-path collective per step.  Weak scaling: every
+rank renders K frames.  Without a launcher (`WORLD_SIZE` unset) `--gpus N` starts the N ranks itself, before
+anything in this process has touched a GPU.  Rank 0 prints one JSON line.
+
+The line carries two timed legs of the same workload: `value` / `roofline` for the default binning
+(tile_rect = 1: a Gaussian is binned into the bounding box of its alpha >= 1/255 region) and `upstream_rect`
+for the reference's own binning (tile_rect = 0: the 3-sigma square, whose tile lists, ranges and num_rendered
+are upstream's bit for bit).  At N = 1 it also holds `roofline.traffic` (HBM bytes of the dominant kernel) and
+`roofline.valu` (issued VALU instructions) from rocprofv3 --pmc passes over a few frames of the same workload,
+run as child processes of this command before it touches the GPU itself (--no-pmc skips them).
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import re
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,7 +43,9 @@ for p in (ROOT, os.path.join(ROOT, "3dgs-avatar-release_amd"), os.path.join(ROOT
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (spec)
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD-32 for 2 cycles
 
 WORKLOADS = {
     # name: (N, W, H, sh_degree, heavy_tail, backward)
@@ -38,6 +55,10 @@ WORKLOADS = {
     "config5": (500000, 2048, 2048, 3, 0.05, True),
     "tiny": (20000, 256, 256, 3, 0.0, True),
 }
+
+# kernel (rocprofv3 name) -> bench stage it belongs to
+KERNEL_STAGE = {"preprocess_kernel": "preprocess", "render_fwd_kernel": "render_fwd", "render_bwd_kernel": "render_bwd",
+                "segment_reduce_kernel": "gaussian_bwd", "gaussian_bwd_kernel": "gaussian_bwd"}
 
 
 def stage_bytes(N, D, px, sh=True):
@@ -53,7 +74,13 @@ def stage_bytes(N, D, px, sh=True):
     }
 
 
-def main():
+def stage_flops(D):
+    """SURVEY.md 8(d) secondary accounting: ~25 flop + 1 exp per (pixel, Gaussian) pair forward, ~70 + 1 exp
+    backward, pairs = 256 D (an upper bound: pairs the kernels cull are never evaluated)."""
+    return {"render_fwd": 256.0 * D * 26, "render_bwd": 256.0 * D * 71}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -74,12 +101,116 @@ def main():
                          "update of all parameters (fused N4 ops)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--no-upstream-leg", action="store_true", help="skip the second timed leg (tile_rect = 0)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / valu become null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 wraps: frames only
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks (this process has not touched a GPU yet)
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: run `python -m torch.distributed.run --nproc-per-node N`
+    on this same file as a CHILD process (never an exec), relay its output, return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ------------------------------------------------------------------------------------------------
+# rocprofv3 --pmc child passes (N = 1 only; before this process touches the GPU)
+# ------------------------------------------------------------------------------------------------
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]]
+
+
+def _short_kernel(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"^void\s+", "", name)
+    name = re.sub(r"<.*$", "", name)
+    return name.strip()
+
+
+def pmc_passes(args, argv):
+    """Mean counter value per launch and kernel over a few frames of this workload: one rocprofv3 child per
+    counter group (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc alone, no trace
+    options).  Returns ({kernel: {counter: mean}}, note) -- ({}, reason) when rocprofv3 is missing or a pass fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    child_args = [a for a in argv if a not in ("--no-cpu-baseline",)]
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="gsplat_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=tmp)
+    try:
+        for counters in PMC_PASSES:
+            out = os.path.join(tmp, "_".join(counters)[:40])
+            cmd = [exe, "--pmc"] + counters + ["-d", out, "--output-format", "csv", "--", sys.executable,
+                                               os.path.abspath(__file__)] + child_args + ["--pmc-child"]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except subprocess.TimeoutExpired:
+                return {}, "rocprofv3 pass timed out (%s)" % ",".join(counters)
+            if r.returncode != 0:
+                return {}, "rocprofv3 pass failed (%s): rc %d" % (",".join(counters), r.returncode)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return {}, "rocprofv3 pass wrote no counter file (%s)" % ",".join(counters)
+            for f in files:
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        k = _short_kernel(row["Kernel_Name"])
+                        a = acc.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                        a[0] += float(row["Counter_Value"])
+                        a[1] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
+    return res, "rocprofv3 --pmc child passes of this command (%s), mean per launch" % " | ".join(",".join(c) for c in PMC_PASSES)
+
+
+def traffic_bytes(c):
+    """HBM bytes of one launch from FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KiB).  On gfx950 FETCH_SIZE counts a
+    128-byte request as 64 bytes for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) and is
+    uncalibrated for other shapes, so both readings are given: `lo` takes FETCH_SIZE as it stands (right for
+    requests of <= 64 B: record gathers, 32-byte rows), `hi` doubles it (right for 16-B-per-lane streams)."""
+    if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    f, w = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+    return {"lo": int(f + w), "hi": int(2 * f + w), "fetch_raw": int(f), "write": int(w)}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(args, argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    pmc, pmc_note = {}, "skipped (--no-pmc)"
+    if world == 1 and not args.pmc_child and not args.no_pmc:
+        pmc, pmc_note = pmc_passes(args, argv)  # children; this process has not initialised the GPU yet
+
     rehearsal = False
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -94,11 +225,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    import diff_gaussian_rasterization as dgr
     from gsplat_mi355 import _lib
     from gsplat_mi355.camera import orbit_camera
+    from gsplat_mi355.debug import frame_stats
     from gsplat_mi355.render import Pipe, l1_loss, render, ssim
     from gsplat_mi355.scenes import GaussianCloud, synthetic_cloud
     from gsplat_mi355.sharding import broadcast_cloud, frames_of_rank
@@ -176,69 +310,125 @@ def main():
                 pkg = render(cams[i], cloud, pipe, bg)
         return pkg
 
-    # ---- untimed: a few steps with every stage bracketed by HIP events -> dominant kernel
-    for i in range(3):
-        step(i)
-    torch.cuda.synchronize()
-    _lib.profile_enable(True)
-    for i in range(3, 8):
-        pkg = step(i)
-    stages = _lib.profile_collect()
-    _lib.profile_enable(False)
-    stage_ms = {k: v[0] / 5.0 for k, v in stages.items()}  # ms per frame (5 profiled frames)
+    if args.pmc_child:  # under rocprofv3 --pmc: a few frames, nothing timed, nothing printed
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        return
+
     groups = {"preprocess": ["preprocess"], "binning": ["depth_sort", "scan", "emit", "tile_sort", "ranges"],
               "render_fwd": ["render_fwd"], "render_bwd": ["render_bwd"], "gaussian_bwd": ["gaussian_bwd"]}
     kernel_stages = ["preprocess", "render_fwd", "render_bwd", "gaussian_bwd"]
-    dominant = max(kernel_stages, key=lambda k: stage_ms.get(k, 0.0))
 
-    # D and n_contrib of the benchmark frame (reported with every number: cost is a function of D)
-    with torch.no_grad():
-        vis = int((pkg.radii > 0).sum().item())
-    from gsplat_mi355.debug import frame_stats
-    D, mean_contrib = frame_stats(cams[0], cloud, pipe, bg)
-
-    # ---- warmup + timed region
-    for i in range(Wm):
-        step(8 + i)
-    _lib.profile_enable(True, stage=dominant)  # two HIP events per step around the dominant kernel only
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(8 + Wm + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dom = _lib.profile_collect().get(dominant, (0.0, 0))
-    _lib.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
+    def run_leg(tile_rect):
+        """One complete measurement in one binning mode: per-stage HIP events on 5 untimed frames, W warm-up steps,
+        then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks."""
+        dgr._TILE_RECT = tile_rect
+        dgr.release_shared_geometry()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for i in range(3, 8):
+            pkg = step(i)
+        stages = _lib.profile_collect()
+        _lib.profile_enable(False)
+        stage_ms = {k: v[0] / 5.0 for k, v in stages.items()}  # ms per frame (5 profiled frames)
+        dominant = max(kernel_stages, key=lambda k: stage_ms.get(k, 0.0))
+        # D and n_contrib of the benchmark frame (reported with every number: cost is a function of D)
+        with torch.no_grad():
+            vis = int((pkg.radii > 0).sum().item())
+        D, mean_contrib = frame_stats(cams[0], cloud, pipe, bg)
+        for i in range(Wm):
+            step(8 + i)
+        _lib.profile_enable(True, stage=dominant)  # two HIP events per step around the dominant kernel only
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(8 + Wm + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        dom = _lib.profile_collect().get(dominant, (0.0, 0))
+        _lib.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         px = W * H
         sb = stage_bytes(N, D, px)
         dom_ms = dom[0] / max(dom[1], 1)
         achieved = sb[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_bytes = sum(sb.values()) if do_bwd else sb["preprocess"] + sb["binning"] + sb["render_fwd"]
-        fps = world * K / elapsed
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dominant)
-            except Exception:
-                traffic = None
+        return {
+            "fps": world * K / elapsed, "ms_per_step": elapsed / K * 1e3, "elapsed": elapsed, "D": D, "visible": vis,
+            "mean_contrib": mean_contrib, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
+                         "frame_algorithmic_bytes": frame_bytes,
+                         "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {g: round(sum(stage_ms.get(s, 0.0) for s in ss), 4) for g, ss in groups.items()},
+        }
+
+    default_rect = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
+    main_leg = run_leg(default_rect)
+    up_leg = None
+    if not args.no_upstream_leg and default_rect != 0:
+        up_leg = run_leg(0)
+        dgr._TILE_RECT = default_rect
+        dgr.release_shared_geometry()
+
+    if rank == 0:
+        roof = main_leg["roofline"]
+        dominant = main_leg["dominant"]
+        # ---- measured HBM traffic and VALU issue of the render kernels (rocprofv3 --pmc children of THIS run)
+        per_kernel = {}
+        for kname, stage in KERNEL_STAGE.items():
+            c = pmc.get(kname)
+            if c:
+                per_kernel[kname] = {"stage": stage, "traffic": traffic_bytes(c),
+                                     "valu_insts": int(c["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in c else None}
+        dom_kernels = [k for k, st in KERNEL_STAGE.items() if st == dominant and k in per_kernel and per_kernel[k]["traffic"]]
+        if dom_kernels:
+            lo = sum(per_kernel[k]["traffic"]["lo"] for k in dom_kernels)
+            hi = sum(per_kernel[k]["traffic"]["hi"] for k in dom_kernels)
+            # the render kernels read by 48-byte record gathers and write 32-byte rows (requests <= 64 B): FETCH_SIZE
+            # as it stands; the per-Gaussian kernels stream 16 B per lane: FETCH_SIZE doubled (see traffic_bytes)
+            roof["traffic"] = lo if dominant in ("render_fwd", "render_bwd") else hi
+            roof["traffic_range"] = [lo, hi]
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
+        roof["traffic_source"] = pmc_note
+        fl = stage_flops(main_leg["D"])
+        valu = {}
+        for kname, stage in (("render_fwd_kernel", "render_fwd"), ("render_bwd_kernel", "render_bwd")):
+            ms = main_leg["dom_ms"] if stage == dominant else main_leg["stage_ms"].get(stage, 0.0)
+            if ms <= 0:
+                continue
+            rec = {"kernel_ms": round(ms, 4),
+                   "flops_8d": fl[stage], "tflops_8d": round(fl[stage] / (ms * 1e-3) / 1e12, 2),
+                   "frac_of_fp32_vector_peak": round(fl[stage] / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+            insts = per_kernel.get(kname, {}).get("valu_insts")
+            if insts:
+                # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles: slots = SIMDs x clock x t / 2
+                rec["insts_per_launch"] = insts
+                rec["issue_slot_util"] = round(insts * 2.0 / (SIMDS * CLOCK_HZ * ms * 1e-3), 4)
+            valu[stage] = rec
+        roof["valu"] = {"peak_tflops": VALU_PEAK_TFLOPS, "simds": SIMDS, "clock_hz": CLOCK_HZ,
+                        "note": "secondary ceiling (SURVEY.md 8d): the render kernels are VALU-issue bound, not HBM bound; "
+                                "issue_slot_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
+                                "flops_8d counts 256 D pairs (culled pairs included: an upper bound)",
+                        **valu}
         out = {
             "metric": "render fps (fwd+bwd) @200k Gaussians 1024x1024 SH3" if args.workload == "config3"
             else "render fps (%s) @%s" % ("fwd+bwd" if do_bwd else "fwd", args.workload),
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(main_leg["fps"], 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(main_leg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
@@ -246,17 +436,24 @@ def main():
                 (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "") +
                 (", + densification statistics + Adam step" if args.train_step else "") +
                 ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
-                "tile_rect": int(os.environ.get("GSPLAT_TILE_RECT", "1")), "gaussians": N, "visible": vis, "width": W, "height": H, "sh_degree": deg, "num_rendered": D,
-                "mean_n_contrib": round(mean_contrib, 2), "frames_per_rank": K, "parallelism": "frames sharded x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
+                "tile_rect": default_rect, "gaussians": N, "visible": main_leg["visible"], "width": W, "height": H,
+                "sh_degree": deg, "num_rendered": main_leg["D"], "mean_n_contrib": round(main_leg["mean_contrib"], 2),
+                "frames_per_rank": K, "ranks": world,
+                "backend": "none" if world == 1 else ("gloo (REHEARSAL: all ranks on one GPU)" if rehearsal else "nccl (RCCL)"),
+                "parallelism": "frames sharded x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
                 "broadcast_s": round(t_bcast, 6)},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
-                         "frame_algorithmic_bytes": frame_bytes,
-                         "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
-            "stages_ms": {g: round(sum(stage_ms.get(s, 0.0) for s in ss), 4) for g, ss in groups.items()},
-            "stages_detail_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
+            "roofline": roof,
+            "stages_ms": main_leg["stages_ms"],
+            "stages_detail_ms": {k: round(v, 4) for k, v in sorted(main_leg["stage_ms"].items())},
         }
+        if up_leg is not None:
+            # the reference's own binning (3-sigma squares): tile lists / ranges / num_rendered are upstream's bit for bit
+            out["upstream_rect"] = {"tile_rect": 0, "value": round(up_leg["fps"], 2), "unit": "frames/s",
+                                    "ms_per_step": round(up_leg["ms_per_step"], 4), "num_rendered": up_leg["D"],
+                                    "mean_n_contrib": round(up_leg["mean_contrib"], 2), "roofline": up_leg["roofline"],
+                                    "stages_ms": up_leg["stages_ms"]}
+        if per_kernel:
+            out["pmc_per_kernel"] = per_kernel
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cloud, W, H, deg, gt, do_bwd, args.cpu_threads)
         print(json.dumps(out), flush=True)

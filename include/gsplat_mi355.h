@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define GS_OK 0
-#define GS_E_BAD_ARG (-1)      /* NULL required pointer, non-positive size, bad sh degree   */
+#define GS_E_BAD_ARG (-1)      /* NULL required pointer, non-positive size, bad sh degree, M > 16, rotations / dL_drotations not 16-byte aligned */
 #define GS_E_EXCLUSIVE (-2)    /* both / neither of (shs | colors_precomp) or (scales+rotations | cov3D_precomp) */
 #define GS_E_TOO_LARGE (-3)    /* num_rendered or tile count exceeds the 32-bit index space  */
 #define GS_E_HIP (-4)          /* a HIP launch or API call failed (see gs_last_hip_error)    */
@@ -40,7 +40,7 @@ extern "C" {
  * (gaussian_renderer/__init__.py:85-98) plus the tensors of GaussianRasterizer.forward
  * (:121-129), flattened.  Shapes (fp32, contiguous): means3D[P,3], opacities[P], shs[P,M,3]
  * (coefficient-major, channel-minor; scene/gaussian_model.py:145-148), colors_precomp[P,3],
- * scales[P,3], rotations[P,4] (w,x,y,z; utils/general_utils.py:94-97), cov3D_precomp[P,6]
+ * scales[P,3], rotations[P,4] (w,x,y,z; utils/general_utils.py:94-97; 16-byte aligned), cov3D_precomp[P,6]
  * ([xx,xy,xz,yy,yz,zz]; utils/general_utils.py:73-85), viewmatrix[16] and projmatrix[16]
  * (row-vector convention, scene/cameras.py:35-39), campos[3], bg[3]. */
 typedef struct GsFwdArgs {

@@ -230,7 +230,17 @@ int or_preprocess(const OrArgs* a, float* depths, int* radii, float* xy, float* 
                 float m; memcpy(&m, &mu, 4);
                 const float lm = (m < 1.5f) ? (m - 1.0f) : (0.405465126f + (m - 1.5f) * 0.666666687f);
                 const float thr = 2.0f * ((float)e * 0.693147182f + lm) + 0.002f;
-                const float hx = fminf(sqrtf(thr * cov[0]), 1.0e7f), hy = fminf(sqrtf(thr * cov[2]), 1.0e7f);
+                /* the pixels evaluate the form with the rounded fp32 conic: for an ill-conditioned covariance its level
+                 * set is the exact ellipse scaled by up to sqrt(1 + k 2^-24 a c / det); widen the threshold by that
+                 * (k = 32), and keep the square when the bound says nothing */
+                const float cond = (cov[0] * cov[2]) / det;
+                const float widen = 1.0f + cond * 1.9073486e-6f;
+                float hx = 1.0e7f, hy = 1.0e7f;
+                if (det > 0.0f && widen <= 2.0f) {
+                    const float thr_w = thr * widen;
+                    hx = fminf(sqrtf(thr_w * cov[0]), 1.0e7f);
+                    hy = fminf(sqrtf(thr_w * cov[2]), 1.0e7f);
+                }
                 int sminx = (int)((px - hx) / BLOCK_X), sminy = (int)((py - hy) / BLOCK_Y);
                 int smaxx = (int)((px + hx) / BLOCK_X) + 1, smaxy = (int)((py + hy) / BLOCK_Y) + 1;
                 if (sminx > minx) minx = sminx;

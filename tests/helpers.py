@@ -18,6 +18,20 @@ def cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=0, dist2_fn=None, heavy
     return cloud, cam
 
 
+def needle_cloud_and_camera(n, W, H, seed=0, major=(0.15, 0.7), sh_degree=1):
+    """Long thin Gaussians lying in the image plane (sigma_major hundreds of pixels, sigma_minor at the 0.3 px^2
+    low-pass floor, random in-plane angles): their 2-D covariance determinant is a difference of nearly equal numbers,
+    the stress case for anything derived from the covariance next to the rounded fp32 conic."""
+    cloud, cam = cloud_and_camera(n, W, H, sh_degree=sh_degree, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    cloud.xyz = torch.cat([torch.empty(n, 2).uniform_(-0.4, 0.4, generator=g), torch.empty(n, 1).uniform_(-0.3, 0.3, generator=g)], 1)
+    th = torch.empty(n).uniform_(0, math.pi, generator=g)
+    cloud.rotations = torch.stack([torch.cos(th / 2), torch.zeros(n), torch.zeros(n), torch.sin(th / 2)], 1).contiguous()
+    cloud.scales = torch.cat([torch.empty(n, 1).uniform_(*major, generator=g), torch.full((n, 2), 1e-4)], 1).contiguous()
+    cloud.opacity = torch.empty(n, 1).uniform_(0.05, 0.99, generator=g)
+    return cloud, cam
+
+
 def product_tile_rect():
     """The tile-rectangle mode the product runs with (GsFwdArgs.tile_rect; GSPLAT_TILE_RECT, default 1): the oracle is
     put in the same mode wherever internal buffers (tiles_touched, lists, ranges) are compared."""

@@ -68,6 +68,12 @@ def test_argument_validation_without_a_device(lib):
     a.sh_degree = 3  # M too small for the degree
     assert L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None) == -1
     a.sh_degree = 0
+    a.M = 17  # more SH coefficients than degree 3 has: the backward's LDS tile is sized for M <= 16
+    assert L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None) == -1
+    a.M = 1
+    a.rotations = fake + 4  # quaternions are read as float4
+    assert L.gs_forward_preprocess(ctypes.byref(a), fake, 1 << 30, fake, 1 << 30, fake, None, None) == -1
+    a.rotations = fake
     assert L.gs_forward_preprocess(ctypes.byref(a), fake, 16, fake, 1 << 30, fake, None, None) == -5  # workspace too small
     with pytest.raises(RuntimeError, match="exactly one of"):
         lib.check(-2)

@@ -433,3 +433,20 @@ def test_snug_tile_rectangles_change_no_output(oracle):
     for k in b0:
         if b0[k] is not None and isinstance(b0[k], np.ndarray):
             assert np.array_equal(b0[k], b1[k]), k
+
+
+def test_snug_tile_rectangles_stay_conservative_for_needle_gaussians(oracle):
+    """Long thin Gaussians (sigma_major ~100-470 px at 2048^2, thin axis at the low-pass floor): the per-pixel alpha
+    test runs on the rounded fp32 conic, whose determinant cancels, so its alpha >= 1/255 region reaches beyond the
+    exact ellipse's bounding box (by ~15 px at 450 px).  The box is widened by the conditioning bound
+    (gs_math.h: snug_half_widths), so colour and final_T stay BITWISE those of upstream's squares."""
+    n, W, H = 200, 2048, 2048
+    for seed in (0, 1):
+        cloud, cam = helpers.needle_cloud_and_camera(n, W, H, seed=seed)
+        out = {}
+        for mode in (0, 1):
+            out[mode] = oracle.forward(helpers.oracle_scene(cloud, cam, bg=(0.1, 0.2, 0.3), tile_rect=mode))
+        assert out[0]["radii"].max() > 1000
+        assert out[1]["binning"]["D"] < 0.6 * out[0]["binning"]["D"]
+        assert np.array_equal(out[0]["color"], out[1]["color"])
+        assert np.array_equal(out[0]["image"]["final_T"], out[1]["image"]["final_T"])

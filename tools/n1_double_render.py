@@ -22,7 +22,7 @@ for mode in ("separate", "shared", "fused", "separate", "shared", "fused"):
     share = mode == "shared"
     pipe = Pipe(compute_cov3D_python=False, fuse_opacity=(mode == "fused"))
     dgr._SHARE = share
-    dgr._geom_cache.entry.clear()
+    dgr.release_shared_geometry()
     for i in range(5):
         for f in GaussianCloud.FIELDS: getattr(cloud, f).grad = None
         train_step(cams[i], cloud, pipe, bg, gt, gt_mask=mask, lambda_mask=0.1)
