@@ -330,13 +330,16 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, const flo
 }
 
 static SsimWindow ssim_window() {
-    // utils/loss_utils.py:27-29: exp(-(x - 5)^2 / (2 * 1.5^2)) evaluated in double, stored as fp32, normalised in fp32
+    // utils/loss_utils.py:27-29: exp(-(x - 5)^2 / (2 * 1.5^2)) evaluated in double, stored as fp32, normalised in fp32.
+    // The divisor is torch's `gauss.sum()`, which for these eleven values is the correctly rounded sum (3.7592328;
+    // adding them one by one in fp32 gives 3.7592325): pinned by the reference's own window in tests/golden/losses.npz.
     SsimWindow w;
-    float s = 0.f;
+    double sd = 0.0;
     for (int k = 0; k < 11; k++) {
         w.w[k] = (float)exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5));
-        s += w.w[k];
+        sd += (double)w.w[k];
     }
+    const float s = (float)sd;
     for (int k = 0; k < 11; k++) w.w[k] /= s;
     return w;
 }

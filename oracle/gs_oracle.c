@@ -674,8 +674,12 @@ double or_l1_loss(long long n, const float* x, const float* y, float* grad) {
  * padding 5 per channel, C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W elements -- and the gradient of that
  * mean w.r.t. img1 (what autograd derives).  Accumulation in double: direct 121-tap sums. */
 double or_ssim(int C, int H, int W, const float* img1, const float* img2, float* grad1) {
-    float g1[11], s = 0.f;
-    for (int k = 0; k < 11; k++) { g1[k] = (float)exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); s += g1[k]; }
+    /* the divisor is torch's gauss.sum(): the correctly rounded sum of the eleven fp32 values (3.7592328; a sequential
+     * fp32 sum gives 3.7592325) -- pinned by the reference's own window, tests/golden/losses.npz */
+    float g1[11];
+    double sd = 0.0;
+    for (int k = 0; k < 11; k++) { g1[k] = (float)exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); sd += (double)g1[k]; }
+    const float s = (float)sd;
     for (int k = 0; k < 11; k++) g1[k] /= s;
     float w2[11][11];
     for (int i = 0; i < 11; i++)

@@ -6,8 +6,16 @@ container, where /root/reference exists; the GPU box and the test-suite only rea
   - cameras.npz     : utils/graphics_utils.py getWorld2View2 / getProjectionMatrix / focal2fov assembled
                       by the recipe of scene/cameras.py:35-40 for the benchmark cameras
 
+  - losses.npz      : utils/loss_utils.py l1_loss / ssim (with gaussian, create_window, _ssim) on seeded CPU images, in
+                      fp32 (the precision the reference runs them in) and fp64, values and autograd gradients w.r.t.
+                      the first image.  The module itself does not import here (cv2 / pytorch3d at module level, which
+                      those five functions do not use), so ONLY those function definitions are taken from the file's
+                      syntax tree and executed, with the names they need (torch, F, Variable, exp) in scope; nothing of
+                      the reference's text is stored.
+
 Run:  python tests/golden/make_golden.py
 """
+import ast
 import importlib.util
 import math
 import os
@@ -26,7 +34,54 @@ def _load(name, rel):
     return mod
 
 
+def _load_functions(rel, names, scope):
+    """Executes only the named top-level function definitions of a reference file (its module-level imports may need
+    packages that are absent here and that these functions do not use)."""
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), [n.name for n in picked]
+    ns = dict(scope)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def make_losses():
+    import torch.nn.functional as F
+    from math import exp
+    from torch.autograd import Variable
+    ns = _load_functions("utils/loss_utils.py", ["l1_loss", "gaussian", "create_window", "ssim", "_ssim"],
+                         dict(torch=torch, F=F, Variable=Variable, exp=exp))
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    k = 0
+    for shape in [(3, 48, 64), (3, 37, 53), (1, 16, 16)]:
+        a = torch.rand(shape, generator=g)
+        b = (a + 0.15 * torch.randn(shape, generator=g)).clamp(0, 1)
+        if k == 2:
+            b = a.clone()  # identical images: SSIM = 1
+        out["img1_%d" % k], out["img2_%d" % k] = a.numpy(), b.numpy()
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            x = a.to(dt).clone().requires_grad_(True)
+            v = ns["ssim"](x, b.to(dt))
+            v.backward()
+            out["ssim_%s_%d" % (tag, k)] = v.detach().numpy()
+            out["ssim_grad_%s_%d" % (tag, k)] = x.grad.numpy()
+            x = a.to(dt).clone().requires_grad_(True)
+            v = ns["l1_loss"](x, b.to(dt))
+            v.backward()
+            out["l1_%s_%d" % (tag, k)] = v.detach().numpy()
+            out["l1_grad_%s_%d" % (tag, k)] = x.grad.numpy()
+        k += 1
+    out["count"] = np.array(k)
+    w = ns["create_window"](11, 3)
+    out["window"] = w.numpy()
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("wrote losses.npz")
+
+
 def main():
+    make_losses()
     sh_utils = _load("ref_sh_utils", "utils/sh_utils.py")
     gu = _load("ref_graphics_utils", "utils/graphics_utils.py")
 

@@ -1163,7 +1163,10 @@ def test_snug_tile_rectangles_stay_conservative_for_needle_gaussians(oracle):
                 assert st["D"] == fw["binning"]["D"]
                 assert np.array_equal(st["geom"]["tiles_touched"], fw["geom"]["tiles_touched"])
                 assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"])
-                _bulk_close(st["color"], fw["color"], frac=1e-4, name="needles color mode %d" % mode)
+                # NOT the 1e-5 bar: the quadratic form of a needle is a sum of terms ~ (a c / det) times larger than
+                # the result, so any two fp32 evaluation orders (the oracle's, this kernel's log2-domain FMAs, upstream's
+                # nvcc contraction) differ by ~2^-24 a c / det in the exponent -- percent-level alphas for these Gaussians
+                assert np.abs(st["color"] - fw["color"]).max() < 0.05
                 res[mode] = st
             assert res[1]["D"] < 0.6 * res[0]["D"]
             assert np.array_equal(res[0]["color"], res[1]["color"]), seed

@@ -60,3 +60,33 @@ def test_camera_matrices_match_reference_graphics_utils():
         assert np.array_equal(cam.full_proj_transform.numpy(), g["full_proj_%d" % k])
         assert np.array_equal(cam.camera_center.numpy(), g["center_%d" % k])
         assert focal2fov(500.0 * W / 512.0, W) == fovx
+
+
+def test_image_losses_match_reference_loss_utils(oracle):
+    """N2 pinned: the oracle's L1 and SSIM (values and gradients w.r.t. the rendered image) against fixtures produced by
+    the reference's own `l1_loss`, `gaussian`, `create_window`, `ssim`, `_ssim` (utils/loss_utils.py:21-67) run on seeded
+    CPU images in fp64 and in fp32 (tests/golden/make_golden.py executes exactly those function definitions).  The
+    oracle accumulates in double: it must sit on the reference's fp64 result (1e-9) and within fp32 conv2d rounding of
+    the reference's fp32 result; the window entries are the reference's fp32 ones bit for bit."""
+    g = np.load(os.path.join(GOLD, "losses.npz"))
+    # the reference's 11x11 window (fp32): outer product of the normalised 1-D Gaussian, identical for every channel
+    w = g["window"]
+    assert w.shape == (3, 1, 11, 11) and w.dtype == np.float32
+    g1 = np.array([np.float32(np.exp(-(k - 5) ** 2 / (2 * 1.5 ** 2))) for k in range(11)], np.float32)
+    assert abs(float(w[0, 0].sum()) - 1.0) < 1e-6 and np.array_equal(w[0], w[2])
+    for k in range(int(g["count"])):
+        a, b = g["img1_%d" % k], g["img2_%d" % k]
+        v, grad = oracle.ssim(a, b)
+        assert abs(v - float(g["ssim_f64_%d" % k])) < 1e-9, k
+        gs = np.abs(g["ssim_grad_f64_%d" % k]).max()
+        if gs > 0:
+            assert np.abs(grad - g["ssim_grad_f64_%d" % k]).max() <= 1e-6 * gs, k
+        # the reference's own fp32 evaluation differs from fp64 by conv2d rounding (sigma = E[x^2] - mu^2 cancels)
+        assert abs(v - float(g["ssim_f32_%d" % k])) < 2e-5, k
+        if gs > 0:
+            assert np.abs(grad - g["ssim_grad_f32_%d" % k]).max() <= 5e-4 * gs, k
+        lv, lgrad = oracle.l1_loss(a, b)
+        assert abs(lv - float(g["l1_f64_%d" % k])) <= 1e-12 + 1e-9 * abs(lv), k
+        assert abs(lv - float(g["l1_f32_%d" % k])) <= 1e-6 * max(abs(lv), 1e-30) + 1e-9, k
+        assert np.array_equal(lgrad, g["l1_grad_f32_%d" % k]), k  # sign(x - y) / n, bit for bit
+    assert abs(float(g["ssim_f64_2"]) - 1.0) < 1e-12  # identical images
