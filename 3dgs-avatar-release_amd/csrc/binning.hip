@@ -108,13 +108,15 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
 // overlap its chunk in LDS and every pair finds its owner with a binary search over their offsets.
 // Stores are fully coalesced.
 __global__ __launch_bounds__(256) void emit_owner_kernel(const uint32_t* __restrict__ tt_rank,
-                                                         const uint32_t* __restrict__ offs, int P, uint32_t D,
-                                                         uint32_t nchunks, uint32_t* __restrict__ owner, ZeroJob zero_a,
+                                                         const uint32_t* __restrict__ offs, int P, const PairCount pc,
+                                                         uint32_t* __restrict__ owner, ZeroJob zero_a,
                                                          ZeroJob zero_b) {
     zero_job(zero_a);  // the tile sort's digit totals and the tile ranges (saves two fill launches)
     zero_job(zero_b);
+    const uint32_t D = pair_count(pc);
+    const uint32_t nchunks = (D + EMIT_CHUNK - 1) / EMIT_CHUNK;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
+    if (r >= P || D == 0) return;
     const uint32_t tt = tt_rank[r];
     if (!tt) return;
     const uint32_t off = offs[r], last = off + tt - 1;
@@ -126,9 +128,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ offs,
                                                    const uint32_t* __restrict__ owner, float* __restrict__ rec,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                   uint32_t D, uint32_t nchunks, int gx) {
+                                                   const PairCount pc, int gx) {
     __shared__ uint32_t s_off[EMIT_CHUNK + 1], s_idx[EMIT_CHUNK + 1], s_rmin[EMIT_CHUNK + 1], s_rsz[EMIT_CHUNK + 1];
+    const uint32_t D = pair_count(pc);
+    const uint32_t nchunks = (D + EMIT_CHUNK - 1) / EMIT_CHUNK;
     const uint32_t c = blockIdx.x;
+    if (c >= nchunks) return;  // the grid covers the capacity
     const uint32_t o0 = c * EMIT_CHUNK, o1 = min(D, o0 + EMIT_CHUNK);
     const uint32_t r0 = owner[c], r1 = owner[c + 1 < nchunks ? c + 1 : nchunks];
     // every rank in [r0, r1] has at least one pair (Gaussians without tiles sort behind all others), so
@@ -167,22 +172,22 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
 }
 
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, int64_t D, int gx, int debug,
+                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, PairCount pc, int gx, int debug,
                 hipStream_t s) {
-    if (D <= 0) return GS_OK;
-    const uint32_t nchunks = (uint32_t)((D + EMIT_CHUNK - 1) / EMIT_CHUNK);
-    hipLaunchKernelGGL(emit_owner_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tt_rank, offs, P, (uint32_t)D, nchunks,
-                       owner, zero_a, zero_b);
+    if (pc.cap == 0) return GS_OK;
+    const uint32_t nchunks = (uint32_t)(((uint64_t)pc.cap + EMIT_CHUNK - 1) / EMIT_CHUNK);
+    hipLaunchKernelGGL(emit_owner_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tt_rank, offs, P, pc, owner, zero_a,
+                       zero_b);
     GS_LAUNCH_CHECK("emit.owner", debug, s);
-    hipLaunchKernelGGL(emit_kernel, dim3(nchunks), dim3(256), 0, s, sorted_idx, offs, owner, rec, keys, vals, (uint32_t)D,
-                       nchunks, gx);
+    hipLaunchKernelGGL(emit_kernel, dim3(nchunks), dim3(256), 0, s, sorted_idx, offs, owner, rec, keys, vals, pc, gx);
     GS_LAUNCH_CHECK("emit", debug, s);
     return GS_OK;
 }
 
 // ranges[tile] = [first, end) in the sorted list (upstream identifyTileRanges); ranges pre-zeroed.
 __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ tile_sorted,
-                                                     uint32_t* __restrict__ ranges, int64_t D) {
+                                                     uint32_t* __restrict__ ranges, const PairCount pc) {
+    const int64_t D = (int64_t)pair_count(pc);
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
     const uint32_t cur = tile_sorted[j];
@@ -198,14 +203,15 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
     if (j == D - 1) ranges[2 * cur + 1] = (uint32_t)D;
 }
 
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, PairCount pc, int ntiles, bool ranges_zeroed, int debug,
                   hipStream_t s) {
     if (!ranges_zeroed) {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
     }
-    if (D > 0) {
-        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, tile_sorted, ranges, D);
+    if (pc.cap > 0) {
+        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)(((uint64_t)pc.cap + 255) / 256)), dim3(256), 0, s, tile_sorted,
+                           ranges, pc);
         GS_LAUNCH_CHECK("ranges", debug, s);
     }
     return GS_OK;

@@ -142,16 +142,17 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     return forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned, nullptr, stream);
 }
 
-int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
-                      void* img, size_t img_bytes, int64_t D, float* out_color, void* stream) {
-    int rc = validate(a);
-    if (rc != GS_OK) return rc;
-    if (!geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
-    if (D > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
+// Phase 2 against a binning state carved for `cap` pairs.  The kernels read the frame's pair count from the geom state
+// on the device (PairCount): the phase can be enqueued before the host knows the count; a count beyond `cap` makes every
+// kernel do the work of an empty frame (nothing out of bounds) and the caller runs the phase again with a larger state.
+static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
+                          size_t img_bytes, int64_t cap, float* out_color, void* stream) {
+    if (!geom || !img || !out_color || cap < 0 || (cap > 0 && !binning)) return GS_E_BAD_ARG;
+    if (cap > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const GeomLayout L = geom_layout(a->P);
     const ImgLayout I = img_layout(a->W, a->H);
-    const BinLayout B = bin_layout(D);
-    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
+    const BinLayout B = bin_layout(cap);
+    if (geom_bytes < L.total || img_bytes < I.total || (cap > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* g = (char*)geom;
     char* b = (char*)binning;
@@ -159,27 +160,30 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     const int ntiles = I.gx * I.gy;
     uint32_t* ranges = (uint32_t*)(im + I.ranges);
     const uint32_t* point_list = nullptr;
-    if (D > 0) {
+    const unsigned long long* count_dev = (const unsigned long long*)(g + L.count);
+    const PairCount pc{count_dev, (uint32_t)cap};
+    int rc;
+    if (cap > 0) {
         uint32_t* k0 = (uint32_t*)(b + B.key0);
         uint32_t* k1 = (uint32_t*)(b + B.key1);
         uint32_t* v0 = (uint32_t*)(b + B.val0);
         uint32_t* v1 = (uint32_t*)(b + B.val1);
         const int bits = tile_bits(ntiles);
         ZeroJob zt, zr;  // the tile sort's digit totals and the tile ranges, cleared by the emission pre-pass
-        sort_totals_region((uint32_t*)(b + B.hist), D, bits, &zt.ptr, &zt.words);
+        sort_totals_region((uint32_t*)(b + B.hist), cap, bits, &zt.ptr, &zt.words);
         zr.ptr = ranges;
         zr.words = ntiles * 2;
         { StageScope sc_("emit", s);
         rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
-                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), zt, zr, a->P, D, I.gx, a->debug, s); }
+                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), zt, zr, a->P, pc, I.gx, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("tile_sort", s);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), D, bits, true, a->debug, s); }
+        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), cap, bits, true, a->debug, s, count_dev); }
         if (rc != GS_OK) return rc;
         const bool odd = radix_passes(bits) & 1;
         point_list = odd ? v1 : v0;
         { StageScope sc_("ranges", s);
-        rc = launch_ranges(odd ? k1 : k0, ranges, D, ntiles, true, a->debug, s); }
+        rc = launch_ranges(odd ? k1 : k0, ranges, pc, ntiles, true, a->debug, s); }
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
@@ -189,7 +193,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), FillJob{nullptr, 0}, a->debug, s); }
     if (rc != GS_OK) return rc;
     QuadLists ql;
-    ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
+    ql.qlist = cap > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     { StageScope sc_("render_fwd", s);
@@ -203,16 +207,24 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
     return GS_OK;
 }
 
-// Both phases in one call: the only host synchronisation of the forward (the pair count sizes the binning
-// state) is taken here, next to the launches that follow it, so the GPU idles only for the wake-up -- not
-// for the caller's interpreter as well.
-int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
-               size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color, int64_t* num_rendered,
-               void* stream) {
-    if (!count_host_pinned || !num_rendered) return GS_E_BAD_ARG;
-    // The scan kernel stores the count into the pinned word itself and the host polls it: the count arrives a
-    // PCIe write after it exists.  (A copy + hipStreamSynchronize costs ~20 us of wake-up during which the GPU
-    // idles.)  The poll is bounded; past the bound, or without Gaussians, the stream is synchronised instead.
+int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                      void* img, size_t img_bytes, int64_t D, float* out_color, void* stream) {
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    return forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream);
+}
+
+// Both phases in one call, WITHOUT a GPU idle stretch for the pair count.  The binning state the caller passes was
+// carved for `capacity` pairs (gs_binning_bytes(capacity): the caller sizes it from the previous frame's count).
+// Phase 2 is enqueued right behind phase 1, its kernels reading the count on the device; only then does the host wait
+// for the count -- the scan kernel stores it straight into the caller's pinned word -- while the GPU already works on
+// phase 2.  If the count turns out larger than the capacity, phase 2 has rendered an empty frame into the buffers
+// (nothing out of bounds): GS_E_WORKSPACE is returned with *num_rendered set and the caller runs gs_forward_render with
+// a state of the right size.  With capacity 0 (no estimate yet) only phase 1 runs and GS_E_WORKSPACE is returned.
+int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, int64_t capacity,
+               void* img, size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color,
+               int64_t* num_rendered, void* stream) {
+    if (!count_host_pinned || !num_rendered || capacity < 0) return GS_E_BAD_ARG;
     volatile int64_t* word = count_host_pinned;
     const int64_t pending = -1;
     static std::atomic<bool> poll_works{true};  // cleared for the process if a device write to the word is ever not seen
@@ -221,6 +233,11 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
     int rc = forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned,
                             poll ? (unsigned long long*)count_host_pinned : nullptr, stream);
     if (rc != GS_OK) return rc;
+    const bool speculate = capacity > 0 && binning && binning_bytes >= bin_layout(capacity).total && capacity <= GS_MAX_PAIRS;
+    if (speculate) {
+        rc = forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, capacity, out_color, stream);
+        if (rc != GS_OK) return rc;
+    }
     bool have = false;
     if (poll) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -245,8 +262,8 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
     const int64_t D = *word;
     *num_rendered = D;
     if (D > (int64_t)GS_MAX_PAIRS) return GS_E_TOO_LARGE;
-    if (D > 0 && (!binning || binning_bytes < bin_layout(D).total)) return GS_E_WORKSPACE;  // caller sizes it, then phase 2
-    return gs_forward_render(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream);
+    if (!speculate || D > capacity) return GS_E_WORKSPACE;  // caller sizes the state for D, then gs_forward_render
+    return GS_OK;
 }
 
 int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,

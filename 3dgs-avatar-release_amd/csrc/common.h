@@ -124,6 +124,16 @@ __device__ __forceinline__ void zero_job(const ZeroJob z) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;
 }
 
+// The frame's pair count (num_rendered) as the binning kernels see it: read from the geom state on the DEVICE, so that
+// they can be launched -- with grids sized by the CAPACITY the binning state was carved for -- before the host knows
+// the count.  A count beyond the capacity reads as 0: every kernel then does the work of an empty frame and touches
+// nothing out of bounds; the host sees the real count in its pinned word and runs the phase again with a larger state.
+struct PairCount { const unsigned long long* dev; uint32_t cap; };
+__device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
+    const unsigned long long d = *pc.dev;
+    return d <= (unsigned long long)pc.cap ? (uint32_t)d : 0u;
+}
+
 struct StageScope {
     hipStream_t s;
     StageScope(const char* stage, hipStream_t st) : s(st) { gs_prof_begin(stage, st); }
@@ -144,8 +154,9 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 // The per-pass digit totals inside it must be zero when the first pass starts: either the sort clears
 // them itself (a fill launch), or the caller has a kernel that runs before it clear the region
 // sort_totals_region() names (`totals_zeroed`).
+// `n_dev` (may be null): the number of elements is read on the device, n is then only their capacity (grid sizes).
 int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                      bool totals_zeroed, int debug, hipStream_t s);
+                      bool totals_zeroed, int debug, hipStream_t s, const unsigned long long* n_dev = nullptr);
 static inline void sort_totals_region(uint32_t* hist, int64_t n, int bits, uint32_t** ptr, int* words) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     const size_t items = nn <= (size_t)SORT_SMALL_N ? 1024 : SORT_ITEMS;
@@ -158,9 +169,9 @@ int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_
                       uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
                       hipStream_t s);
 int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, int64_t D, int gx, int debug,
+                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, PairCount pc, int gx, int debug,
                 hipStream_t s);
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, int64_t D, int ntiles, bool ranges_zeroed, int debug,
+int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, PairCount pc, int ntiles, bool ranges_zeroed, int debug,
                   hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)

@@ -28,10 +28,12 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
 // resolves equal addresses inside one instruction at a word per clock, which beats matching equal
 // digits with ballots first), summed over the four waves at the end.
 template <int RS_ROUNDS>
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                             const unsigned long long* __restrict__ n_dev, int shift,
                                                              int dbits, uint32_t* __restrict__ hist, int nblk,
                                                              uint32_t* __restrict__ totals) {
     __shared__ uint32_t h[4][256];
+    if (n_dev) { const unsigned long long d = *n_dev; n = d <= (unsigned long long)n ? (int64_t)d : 0; }  // count on the device, n = capacity
     const int tid = threadIdx.x, wid = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) h[w][tid] = 0;
@@ -110,9 +112,12 @@ template <int RS_ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                int64_t n, int shift, int dbits,
+                                                                int64_t n, const unsigned long long* __restrict__ n_dev,
+                                                                int shift, int dbits,
                                                                 const uint32_t* __restrict__ hist, int nblk) {
     const uint32_t dmask = (1u << dbits) - 1u;
+    if (n_dev) { const unsigned long long d = *n_dev; n = d <= (unsigned long long)n ? (int64_t)d : 0; }
+    if ((int64_t)blockIdx.x * (RS_ROUNDS * RS_THREADS) >= n) return;  // (workgroup-uniform) the grid covers the capacity
     __shared__ uint32_t whist[4][256];
     __shared__ uint32_t delta[256];
     __shared__ uint32_t wsum[4];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
 
 template <int RS_ROUNDS>
 static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                           bool totals_zeroed, int debug, hipStream_t s) {
+                           bool totals_zeroed, int debug, hipStream_t s, const unsigned long long* n_dev) {
     const int items = RS_ROUNDS * RS_THREADS;
     const int nblk = (int)((n + items - 1) / items);
     const int passes = radix_passes(bits);
@@ -211,12 +216,12 @@ static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; p++) {
         const int shift = dbits * p;
-        hipLaunchKernelGGL(rs_hist_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, shift, dbits, hist, nblk,
+        hipLaunchKernelGGL(rs_hist_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, n, n_dev, shift, dbits, hist, nblk,
                            totals + RS_REPL * 256 * p);
         GS_LAUNCH_CHECK("sort.hist", debug, s);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << dbits), dim3(256), 0, s, hist, nblk, totals + RS_REPL * 256 * p);
         GS_LAUNCH_CHECK("sort.scan", debug, s);
-        hipLaunchKernelGGL(rs_scatter_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift,
+        hipLaunchKernelGGL(rs_scatter_kernel<RS_ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, n_dev, shift,
                            dbits, hist, nblk);
         GS_LAUNCH_CHECK("sort.scatter", debug, s);
         uint32_t* t;
@@ -227,9 +232,9 @@ static int sort_pairs_impl(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
 }
 
 int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* hist, int64_t n, int bits,
-                      bool totals_zeroed, int debug, hipStream_t s) {
+                      bool totals_zeroed, int debug, hipStream_t s, const unsigned long long* n_dev) {
     if (n <= 0) return GS_OK;
     // SORT_SMALL_N and the table sizes in the layouts (common.h: sort_table_words, sort_totals_region) go together
-    if (n <= SORT_SMALL_N) return sort_pairs_impl<RS_ROUNDS_SMALL>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s);
-    return sort_pairs_impl<RS_ROUNDS_BIG>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s);
+    if (n <= SORT_SMALL_N) return sort_pairs_impl<RS_ROUNDS_SMALL>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s, n_dev);
+    return sort_pairs_impl<RS_ROUNDS_BIG>(k0, v0, k1, v1, hist, n, bits, totals_zeroed, debug, s, n_dev);
 }

@@ -43,10 +43,11 @@ _SHARE = os.environ.get("GSPLAT_SHARE_GEOMETRY", "1") != "0"
 
 class _GeomEntry(object):
     """Geometry state of ONE forward call (preprocess, sorts, binning), offered to the call that follows it."""
-    __slots__ = ("key", "geom", "binning", "img", "num_rendered", "radii", "__weakref__")
+    __slots__ = ("key", "geom", "binning", "img", "num_rendered", "capacity", "radii", "__weakref__")
 
-    def __init__(self, key, geom, binning, img, num_rendered, radii):
-        self.key, self.geom, self.binning, self.img, self.num_rendered, self.radii = key, geom, binning, img, num_rendered, radii
+    def __init__(self, key, geom, binning, img, num_rendered, capacity, radii):
+        self.key, self.geom, self.binning, self.img, self.radii = key, geom, binning, img, radii
+        self.num_rendered, self.capacity = num_rendered, capacity  # the frame's pair count / what `binning` is carved for
 
     def release(self):
         self.key = self.geom = self.binning = self.img = self.radii = None
@@ -223,7 +224,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.geom_entry = None
             if hit is not None:
                 # same geometry and camera as the call just before: new colours only
-                num_rendered = hit.num_rendered
+                num_rendered, capacity = hit.num_rendered, hit.capacity
                 binning = hit.binning
                 bin_bytes = binning.numel()
                 radii.copy_(hit.radii)
@@ -231,48 +232,49 @@ class _RasterizeGaussians(torch.autograd.Function):
                 check_qlist = binning.clone() if (raster_settings.debug and bin_bytes) else None
                 _lib.check(L.gs_forward_shared(ctypes.byref(a), hit.geom.data_ptr(), hit.img.data_ptr(),
                                                geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes, img.data_ptr(),
-                                               img_bytes, num_rendered, color.data_ptr(), sptr))
+                                               img_bytes, capacity, color.data_ptr(), sptr))
                 if check_qlist is not None and not torch.equal(check_qlist, binning):
                     # the shared binning state belongs to the first call's autograd node as well: the second forward
                     # re-records the quadrant lists, which must come out identical for identical geometry
                     raise RuntimeError("diff_gaussian_rasterization: the shared-geometry render changed the binning "
                                        "state it shares with the previous call")
-                return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp,
+                return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
                                                    img, color, dev, a, sptr)
             count = _pinned_count(dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
-            # previous frame's count (+ 1/8) is handed to gs_forward, which takes the one host sync of the
-            # forward itself and launches phase 2 right behind it; only when the buffer turns out too small
-            # does control come back here to allocate and run phase 2 separately.
+            # previous frame's count (+ 1/8) is handed to gs_forward, which enqueues phase 2 right behind phase 1
+            # against that capacity (the kernels read the count on the device) and only then waits for the count:
+            # the GPU never idles for it.  Only when the count exceeds the capacity (or there is no estimate yet)
+            # does control come back here to allocate and run phase 2 again.
             guess = _last_count.get((dev.index, P, W, H), 0)
-            bin_bytes = _lib.nbytes(L.gs_binning_bytes, guess + guess // 8, W, H) if guess else 0
-            binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if guess else None
+            capacity = guess + guess // 8 if guess else 0
+            bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H) if capacity else 0
+            binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if capacity else None
             nr = ctypes.c_int64(0)
-            rc = L.gs_forward(ctypes.byref(a), geom.data_ptr(), geom_bytes, _lib.ptr(binning), bin_bytes, img.data_ptr(),
-                              img_bytes, radii.data_ptr(), count.data_ptr(), color.data_ptr(), ctypes.byref(nr), sptr)
+            rc = L.gs_forward(ctypes.byref(a), geom.data_ptr(), geom_bytes, _lib.ptr(binning), bin_bytes, capacity,
+                              img.data_ptr(), img_bytes, radii.data_ptr(), count.data_ptr(), color.data_ptr(),
+                              ctypes.byref(nr), sptr)
             num_rendered = int(nr.value)
             if rc == _lib.GS_E_WORKSPACE:
-                bin_bytes = _lib.nbytes(L.gs_binning_bytes, num_rendered, W, H)
+                capacity = num_rendered
+                bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H)
                 binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
                 rc = L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
-                                         img.data_ptr(), img_bytes, num_rendered, color.data_ptr(), sptr)
+                                         img.data_ptr(), img_bytes, capacity, color.data_ptr(), sptr)
             _lib.check(rc)
             _last_count[(dev.index, P, W, H)] = num_rendered
-            if binning is None:  # nothing visible on the first call for this shape
-                binning = torch.empty(0, dtype=torch.uint8, device=dev)
-                bin_bytes = 0
             if share:
                 # offered to the next call; owned by this call's autograd node (ctx), not by the cache
-                ctx.geom_entry = _GeomEntry(gkey, geom, binning, img, num_rendered, radii)
+                ctx.geom_entry = _GeomEntry(gkey, geom, binning, img, num_rendered, capacity, radii)
                 _geom_cache.put(dev, ctx.geom_entry)
-            return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities,
-                                               scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color, dev, a,
-                                               sptr)
+            return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
+                                               opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color,
+                                               dev, a, sptr)
 
     @staticmethod
-    def _finish(ctx, raster_settings, num_rendered, means3D, sh, colors_precomp, opacities, scales, rotations,
+    def _finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp, opacities, scales, rotations,
                 cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr):
         opacity = None
         if ctx.with_opacity:
@@ -282,7 +284,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             _lib.check(L.gs_opacity_image(ctypes.byref(a), img.data_ptr(), img.numel(), opacity.data_ptr(), sptr))
         ctx.raster_settings = raster_settings
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = num_rendered  # the frame's pair count (upstream's num_rendered)
+        ctx.capacity = capacity          # pairs the binning state is carved for (>= num_rendered): what the backward is given
         ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D, sh if sh is not None else empty,
@@ -306,7 +309,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         P = int(means3D.shape[0])
         W, H = int(settings.image_width), int(settings.image_height)
-        D = ctx.num_rendered
+        D = ctx.capacity
         if grad_out_color is None:  # only the opacity render was used downstream
             grad_out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         g = _f32c(grad_out_color, "grad_out_color")

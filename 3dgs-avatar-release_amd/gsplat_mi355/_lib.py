@@ -67,8 +67,8 @@ def load():
                                             c_void_p, c_void_p]
         L.gs_forward_render.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
                                         c_int64, c_void_p, c_void_p]
-        L.gs_forward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
-                                 c_void_p, c_void_p, POINTER(c_int64), c_void_p]
+        L.gs_forward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_int64, c_void_p, c_size_t,
+                                 c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p]
         L.gs_forward_shared.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                         c_void_p, c_size_t, c_int64, c_void_p, c_void_p]
         L.gs_backward.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,

@@ -75,7 +75,9 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
 
 
 def frame_stats(cam, cloud, pipe, bg):
-    """(num_rendered D, mean n_contrib per pixel) of one frame: reported beside every benchmark number."""
+    """(num_rendered D, mean n_contrib per pixel, quadrant hits) of one frame: reported beside every benchmark number.
+    Quadrant hits = (8x8 quadrant, Gaussian) entries up to each quadrant's last contributor: what the backward's wave
+    per quadrant iterates over, 64 pixels per entry."""
     import math
     settings = GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
@@ -85,4 +87,4 @@ def frame_stats(cam, cloud, pipe, bg):
     with torch.no_grad():
         st = forward_state(settings, cloud.xyz.detach(), cloud.opacity.detach(), shs=cloud.shs.detach(),
                            scales=cloud.scales.detach(), rotations=cloud.rotations.detach())
-    return int(st["D"]), float(st["image"]["n_contrib"].mean())
+    return int(st["D"]), float(st["image"]["n_contrib"].mean()), int(st["image"]["qcount"].astype("int64").sum())

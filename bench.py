@@ -74,10 +74,10 @@ def stage_bytes(N, D, px, sh=True):
     }
 
 
-def stage_flops(D):
+def stage_flops(pairs):
     """SURVEY.md 8(d) secondary accounting: ~25 flop + 1 exp per (pixel, Gaussian) pair forward, ~70 + 1 exp
-    backward, pairs = 256 D (an upper bound: pairs the kernels cull are never evaluated)."""
-    return {"render_fwd": 256.0 * D * 26, "render_bwd": 256.0 * D * 71}
+    backward."""
+    return {"render_fwd": float(pairs) * 26, "render_bwd": float(pairs) * 71}
 
 
 def parse_args(argv=None):
@@ -182,14 +182,16 @@ def pmc_passes(args, argv):
 
 
 def traffic_bytes(c):
-    """HBM bytes of one launch from FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KiB).  On gfx950 FETCH_SIZE counts a
-    128-byte request as 64 bytes for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) and is
-    uncalibrated for other shapes, so both readings are given: `lo` takes FETCH_SIZE as it stands (right for
-    requests of <= 64 B: record gathers, 32-byte rows), `hi` doubles it (right for 16-B-per-lane streams)."""
+    """HBM-side bytes of one launch from FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KiB): 2 x FETCH_SIZE + WRITE_SIZE.
+    On gfx950 FETCH_SIZE counts every read request of the L2 -- a 128-byte line -- as 64 bytes
+    (MI355X_MICROARCH.md, HBM section, states it for wide streaming reads).  Calibrated for THIS library's access
+    shapes with tools/fetch_calib.hip (profiles/r02_fetch_calibration.md): dword and 16-byte streams, packed 48-byte
+    records in order and at random, records in 128-byte slots and random 32-byte rows all read FETCH_SIZE = 1/2 of the
+    128-byte lines they touch; WRITE_SIZE is exact, also for scattered 32-byte rows."""
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     f, w = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
-    return {"lo": int(f + w), "hi": int(2 * f + w), "fetch_raw": int(f), "write": int(w)}
+    return {"bytes": int(2 * f + w), "fetch_size_raw": int(f), "write_size": int(w)}
 
 
 def main(argv=None):
@@ -338,7 +340,7 @@ def main(argv=None):
         # D and n_contrib of the benchmark frame (reported with every number: cost is a function of D)
         with torch.no_grad():
             vis = int((pkg.radii > 0).sum().item())
-        D, mean_contrib = frame_stats(cams[0], cloud, pipe, bg)
+        D, mean_contrib, quad_hits = frame_stats(cams[0], cloud, pipe, bg)
         for i in range(Wm):
             step(8 + i)
         _lib.profile_enable(True, stage=dominant)  # two HIP events per step around the dominant kernel only
@@ -367,7 +369,7 @@ def main(argv=None):
         frame_bytes = sum(sb.values()) if do_bwd else sb["preprocess"] + sb["binning"] + sb["render_fwd"]
         return {
             "fps": world * K / elapsed, "ms_per_step": elapsed / K * 1e3, "elapsed": elapsed, "D": D, "visible": vis,
-            "mean_contrib": mean_contrib, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
+            "mean_contrib": mean_contrib, "quad_hits": quad_hits, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
@@ -396,21 +398,19 @@ def main(argv=None):
                                      "valu_insts": int(c["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in c else None}
         dom_kernels = [k for k, st in KERNEL_STAGE.items() if st == dominant and k in per_kernel and per_kernel[k]["traffic"]]
         if dom_kernels:
-            lo = sum(per_kernel[k]["traffic"]["lo"] for k in dom_kernels)
-            hi = sum(per_kernel[k]["traffic"]["hi"] for k in dom_kernels)
-            # the render kernels read by 48-byte record gathers and write 32-byte rows (requests <= 64 B): FETCH_SIZE
-            # as it stands; the per-Gaussian kernels stream 16 B per lane: FETCH_SIZE doubled (see traffic_bytes)
-            roof["traffic"] = lo if dominant in ("render_fwd", "render_bwd") else hi
-            roof["traffic_range"] = [lo, hi]
+            roof["traffic"] = sum(per_kernel[k]["traffic"]["bytes"] for k in dom_kernels)
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
         roof["traffic_source"] = pmc_note
-        fl = stage_flops(main_leg["D"])
+        # (pixel, Gaussian) pairs the render kernels evaluate: 64 pixels per (quadrant, Gaussian) entry up to the quadrant's
+        # last contributor (what the backward iterates; the forward stops a little later, when all 64 pixels are done)
+        pairs_eval = 64.0 * main_leg["quad_hits"]
+        fl = stage_flops(pairs_eval)
         valu = {}
         for kname, stage in (("render_fwd_kernel", "render_fwd"), ("render_bwd_kernel", "render_bwd")):
             ms = main_leg["dom_ms"] if stage == dominant else main_leg["stage_ms"].get(stage, 0.0)
             if ms <= 0:
                 continue
-            rec = {"kernel_ms": round(ms, 4),
+            rec = {"kernel_ms": round(ms, 4), "pairs_evaluated": pairs_eval,
                    "flops_8d": fl[stage], "tflops_8d": round(fl[stage] / (ms * 1e-3) / 1e12, 2),
                    "frac_of_fp32_vector_peak": round(fl[stage] / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
             insts = per_kernel.get(kname, {}).get("valu_insts")
@@ -422,7 +422,8 @@ def main(argv=None):
         roof["valu"] = {"peak_tflops": VALU_PEAK_TFLOPS, "simds": SIMDS, "clock_hz": CLOCK_HZ,
                         "note": "secondary ceiling (SURVEY.md 8d): the render kernels are VALU-issue bound, not HBM bound; "
                                 "issue_slot_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
-                                "flops_8d counts 256 D pairs (culled pairs included: an upper bound)",
+                                "flops_8d = SURVEY 8(d)'s 26 / 71 flop per (pixel, Gaussian) pair x the pairs the kernels "
+                                "evaluate (64 x quadrant-list entries up to each quadrant's last contributor)",
                         **valu}
         out = {
             "metric": "render fps (fwd+bwd) @200k Gaussians 1024x1024 SH3" if args.workload == "config3"

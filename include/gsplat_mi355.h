@@ -101,19 +101,26 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
                           int32_t* radii, int64_t* count_host_pinned, void* stream);
 
 /* ---- forward, phase 2 (second half of upstream rasterize_gaussians: duplicateWithKeys, sort,
- * identifyTileRanges, render).  `num_rendered` must be the value phase 1 produced.  Writes
+ * identifyTileRanges, render).  `num_rendered` is the number of pairs the binning state is carved for: the value
+ * phase 1 produced, or any larger capacity (the kernels read the frame's own count from the geom state).  Writes
  * out_color[3,H,W]. */
 int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                       void* img, size_t img_bytes, int64_t num_rendered, float* out_color, void* stream);
 
-/* ---- forward, both phases in one call (the whole of upstream rasterize_gaussians).  Runs phase 1, waits on
- * `stream` for the pair count (the one host synchronisation of the forward), stores it in *num_rendered and,
- * if `binning_bytes` >= gs_binning_bytes(*num_rendered), goes straight on with phase 2.  Otherwise returns
- * GS_E_WORKSPACE with *num_rendered set: the caller allocates the binning state and calls gs_forward_render.
- * Callers pass a binning buffer sized from the previous frame's count so that the second case is rare. */
-int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
-               size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color, int64_t* num_rendered,
-               void* stream);
+/* ---- forward, both phases in one call (the whole of upstream rasterize_gaussians), with NO GPU idle stretch for the
+ * pair count.  Upstream blocks on a device-to-host copy of num_rendered between its two halves, because the count
+ * sizes the binning buffer.  Here the caller passes a binning state sized for `capacity` pairs
+ * (gs_binning_bytes(capacity); e.g. the previous frame's count + 1/8); phase 2 is enqueued right behind phase 1 with
+ * grids sized by the capacity, its kernels reading the count on the device, and only then does the host wait for the
+ * count (stored by the device straight into the HOST-pinned `count_host_pinned`) -- the GPU is already busy with
+ * phase 2.  Returns GS_OK with *num_rendered set when the count fits the capacity.  Returns GS_E_WORKSPACE with
+ * *num_rendered set when it does not (phase 2 has then rendered an empty frame, nothing out of bounds), or when
+ * capacity is 0 (only phase 1 ran): the caller allocates gs_binning_bytes(*num_rendered) and calls
+ * gs_forward_render.  A state carved for `capacity` pairs is passed on with num_rendered = capacity to
+ * gs_backward / gs_forward_shared / gs_binning_field (the carve is a function of that number). */
+int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, int64_t capacity,
+               void* img, size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color,
+               int64_t* num_rendered, void* stream);
 
 /* ---- shared-geometry forward (no upstream counterpart).  The reference's render()
  * rasterizes twice per step with identical geometry -- colour pass, then an opacity pass with
@@ -126,8 +133,9 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
                       float* out_color, void* stream);
 
 /* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
- * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `scratch` holds
- * gs_backward_scratch_bytes(num_rendered, P, W, H) bytes. */
+ * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `num_rendered` is the number of
+ * pairs the forward's binning state was carved for (the capacity given to gs_forward, or the count given to
+ * gs_forward_render).  `scratch` holds gs_backward_scratch_bytes(num_rendered, P, W, H) bytes. */
 int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t num_rendered,
                 const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,

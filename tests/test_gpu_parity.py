@@ -555,6 +555,42 @@ def test_bitwise_determinism_and_debug_mode():
             assert torch.equal(a, b)
 
 
+def test_speculative_binning_capacity_overflow_and_slack_give_the_same_bits():
+    """gs_forward enqueues phase 2 against a binning state sized from the PREVIOUS frame's pair count, before the host
+    knows this frame's count (no GPU idle stretch for it).  Whatever the estimate -- none, far too small (overflow: the
+    speculative phase renders an empty frame and phase 2 is run again on a state of the right size), exact, or far too
+    large -- image, radii and every gradient must be the same bits."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 9000, 272, 200
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=19, scale_mul=1.5)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+    key = (dev.index, n, W, H)
+
+    def run(estimate):
+        dgr.release_shared_geometry()
+        if estimate is None:
+            dgr._last_count.pop(key, None)
+        else:
+            dgr._last_count[key] = estimate
+        leaves = dict(means3D=cloud.xyz.to(dev).requires_grad_(True), means2D=torch.zeros(n, 3, device=dev, requires_grad=True),
+                      opacities=cloud.opacity.to(dev).requires_grad_(True), shs=cloud.shs.to(dev).requires_grad_(True),
+                      scales=cloud.scales.to(dev).requires_grad_(True), rotations=cloud.rotations.to(dev).requires_grad_(True))
+        color, radii = GaussianRasterizer(_settings(cam, cloud, (0.2, 0.1, 0.3), dev))(**leaves)
+        (color * gimg).sum().backward()
+        torch.cuda.synchronize()
+        return [color.detach().clone(), radii.clone()] + [v.grad.clone() for v in leaves.values()], dgr._last_count[key]
+
+    ref, D = run(None)
+    assert D > 50000
+    for estimate in (1000, D // 2, D - 1, D, int(D / 1.125) + 1, 3 * D, 40 * D):
+        got, D2 = run(estimate)
+        assert D2 == D
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), estimate
+
+
 def test_shared_geometry_second_render_is_bitwise_identical(oracle):
     """the opacity pass of render() (same geometry, colours = 1) reuses the first
     call's preprocess / sort / binning.  Its image and gradients must equal the stand-alone call's bit
