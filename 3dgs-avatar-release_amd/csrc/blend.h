@@ -51,7 +51,11 @@ __device__ __forceinline__ bool stage_entry_quad(const float4 r0, const float4 r
             const float b2 = 2.f * B;
             const float qmin = fminf(fminf(edge_min(A, b2, C, x0, y0, y1), edge_min(A, b2, C, x1, y0, y1)),
                                      fminf(edge_min(C, b2, A, y0, x0, x1), edge_min(C, b2, A, y1, x0, x1)));
-            hit = inside || (qmin * 0.9999f - 1e-3f <= two_tau);
+            // relative slack: 1e-4, plus the rounding of a form whose terms cancel (long thin Gaussians): ~2^-24 A C / det
+            // per operation (gs_math.h: snug_half_widths); when the bound says nothing the entry is kept
+            const float detc = A * C - B * B;
+            const float rel = 1e-4f + (A * C) / detc * 1.9073486e-6f;
+            hit = inside || !(detc > 0.f) || !(rel < 0.5f) || (qmin * (1.0f - rel) - 1e-3f <= two_tau);
         }
     }
     s.a = make_float4(gx, gy, (-0.5f * LOG2E_F) * A, -LOG2E_F * B);

@@ -2,12 +2,25 @@
 // the stages; no device allocation, no implicit synchronisation (except in debug mode).
 #include "common.h"
 #include <string.h>
+#include <atomic>
 
 static thread_local int g_last_hip = 0;
 static thread_local const char* g_last_stage = "";
 void gs_set_error(int hip_err, const char* stage) {
     g_last_hip = hip_err;
     g_last_stage = stage;
+}
+
+static std::atomic<int> g_tune[GS_TUNE_COUNT] = {};
+static bool g_tune_init = false;
+static void tune_defaults() {
+    if (g_tune_init) return;
+    g_tune_init = true;
+    g_tune[GS_TUNE_XCD_MAP].store(1);
+}
+int gs_tune_get(int key) {
+    tune_defaults();
+    return (key >= 0 && key < GS_TUNE_COUNT) ? g_tune[key].load(std::memory_order_relaxed) : 0;
 }
 
 // ---- per-stage event timing -------------------------------------------------------------------
@@ -582,6 +595,13 @@ int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches
     g_prof.recs.clear();
     *n_out = n;
     return GS_OK;
+}
+
+int gs_tuning(const char* name, int value) {
+    if (!name) return GS_E_BAD_ARG;
+    tune_defaults();
+    if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    return GS_E_BAD_ARG;
 }
 
 const char* gs_status_string(int code) {

@@ -134,6 +134,26 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
     return d <= (unsigned long long)pc.cap ? (uint32_t)d : 0u;
 }
 
+// Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
+int gs_tune_get(int key);
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_COUNT = 8 };
+
+// Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
+// with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
+// on four different XCDs and each of them fetches the tile's splat records into its own L2.  xmap = 1: the 32
+// workgroups b = 32 g .. 32 g + 31 are 8 tiles x 4 quadrants with slot = 8 g + b % 8 and quadrant = (b / 8) % 4 -- the
+// four quadrants of a tile share b % 8, i.e. an XCD (speed only: nothing depends on the placement).
+__device__ __forceinline__ void render_block_map(int b, int xmap, int* slot, int* q) {
+    if (xmap) {
+        *slot = ((b >> 5) << 3) + (b & 7);
+        *q = (b >> 3) & 3;
+    } else {
+        *slot = b >> 2;
+        *q = b & 3;
+    }
+}
+static inline int render_grid_blocks(int ntiles, int xmap) { return xmap ? ((ntiles + 7) / 8) * 32 : ntiles * 4; }
+
 struct StageScope {
     hipStream_t s;
     StageScope(const char* stage, hipStream_t st) : s(st) { gs_prof_begin(stage, st); }

@@ -96,6 +96,7 @@ template <bool OPA>
 __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order, int W, int H, int gx,
+                                                        int ntiles, int xmap,
                                                         const uint32_t* __restrict__ qlist,
                                                         const uint32_t* __restrict__ ncon_c,
                                                         const uint32_t* __restrict__ qcount,
@@ -110,8 +111,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
     __shared__ float pix[OPA ? 7 : 6][4 * RING_STRIDE];  // (+ the opacity channel's gradient)
-    const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel on the forward's counts)
-    const int q = blockIdx.x & 3;
+    int slot, q;
+    render_block_map((int)blockIdx.x, xmap, &slot, &q);
+    if (slot >= ntiles) return;
+    const int tile = (int)order[slot];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int j = lane & (RING - 1), ring = lane / RING;  // position in the ring / which ring
@@ -309,14 +312,16 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
+    const dim3 grid(render_grid_blocks(gx * gy, xmap));
     if (dL_dopa)
-        hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
-                           out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
+        hipLaunchKernelGGL(render_bwd_kernel<true>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
+                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
     else
-        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, ql.qlist, ql.ncon_c, ql.qcount,
-                           out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
+        hipLaunchKernelGGL(render_bwd_kernel<false>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
+                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

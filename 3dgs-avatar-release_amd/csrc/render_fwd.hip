@@ -22,13 +22,16 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order,
                                                         const float* __restrict__ bg, int W, int H, int gx,
+                                                        int ntiles, int xmap,
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib,
                                                         uint32_t* __restrict__ qlist, uint32_t* __restrict__ ncon_c,
                                                         uint32_t* __restrict__ qcount) {
     __shared__ float4 srec[64 * 3];
-    const int tile = (int)order[blockIdx.x >> 2];  // heaviest tiles first (tile_order_kernel)
-    const int q = blockIdx.x & 3;
+    int slot, q;
+    render_block_map((int)blockIdx.x, xmap, &slot, &q);
+    if (slot >= ntiles) return;
+    const int tile = (int)order[slot];  // heaviest tiles first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
@@ -135,9 +138,10 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
                           const QuadLists& ql, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy * 4), dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                       point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx, out_color, final_T,
-                       n_contrib, ql.qlist, ql.ncon_c, ql.qcount);
+    const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s,
+                       reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg,
+                       W, H, gx, gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }

@@ -39,6 +39,9 @@ class GaussianRasterizationSettings(NamedTuple):
 
 _tls = threading.local()
 _SHARE = os.environ.get("GSPLAT_SHARE_GEOMETRY", "1") != "0"
+# 0: wait for the pair count between the two forward phases, as upstream does (A/B switch; default: phase 2 is enqueued
+# against the previous frame's count before the host knows this frame's)
+_SPECULATE = os.environ.get("GSPLAT_SPECULATE", "1") != "0"
 
 
 class _GeomEntry(object):
@@ -191,6 +194,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, with_opacity=False):
         ctx.with_opacity = bool(with_opacity)
+        # outputs nothing downstream differentiates (always: radii) arrive as None in backward instead of as freshly
+        # filled zero tensors -- one fill launch over P ints per step otherwise
+        ctx.set_materialize_grads(False)
         L = _lib.load()
         means3D = _f32c(means3D, "means3D")
         if means3D is None:
@@ -249,7 +255,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # the GPU never idles for it.  Only when the count exceeds the capacity (or there is no estimate yet)
             # does control come back here to allocate and run phase 2 again.
             guess = _last_count.get((dev.index, P, W, H), 0)
-            capacity = guess + guess // 8 if guess else 0
+            capacity = guess + guess // 8 if (guess and _SPECULATE) else 0
             bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H) if capacity else 0
             binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if capacity else None
             nr = ctypes.c_int64(0)

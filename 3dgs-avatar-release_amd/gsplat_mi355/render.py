@@ -27,17 +27,25 @@ class Pipe(object):
 
 
 class RenderPackage(object):
-    """Result holder with the fields of gaussian_renderer/__init__.py:20-55,146-153."""
+    """Result holder with the fields of gaussian_renderer/__init__.py:20-55,146-153.  `visibility_filter` (= radii > 0,
+    :149) is formed when it is first read: a training step that only feeds `radii` to the fused densification
+    statistics never launches the comparison."""
 
     def __init__(self, **data):
         self.data = data
 
+    def _get(self, item):
+        data = self.__dict__["data"]
+        if item == "visibility_filter" and item not in data:
+            data[item] = data["radii"] > 0
+        return data[item]
+
     def __getitem__(self, item):
-        return self.data[item]
+        return self._get(item)
 
     def __getattr__(self, item):
         try:
-            return self.__dict__["data"][item]
+            return self._get(item)
         except KeyError:
             raise AttributeError(item)
 
@@ -48,11 +56,10 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
     If `colors_precomp` is given it is used (the reference always does: gaussian_renderer/__init__.py:117-124);
     otherwise SHs are handed to the rasterizer for in-kernel SH->RGB (north_star)."""
     xyz = pc.xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # gaussian_renderer/__init__.py:76-80 builds `zeros_like(xyz, requires_grad=True) + 0` and retains its gradient: a
+    # tensor whose only purpose is to receive dL/dmeans2D in `.grad`.  A zero LEAF does that with one fill launch instead
+    # of fill + add + the clone AddBackward makes for the retained gradient (the rasterizer never reads its values).
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
     tanfovx = math.tan(data.FoVx * 0.5)
     tanfovy = math.tan(data.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
@@ -93,7 +100,7 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
                                       cov3D_precomp=cov3D_precomp)
         opacity_image = opacity_image[:1]
     return RenderPackage(deformed_gaussian=pc, render=rendered_image, viewspace_points=screenspace_points,
-                         visibility_filter=radii > 0, radii=radii, opacity_render=opacity_image)
+                         radii=radii, opacity_render=opacity_image)
 
 
 class _L1Loss(torch.autograd.Function):

@@ -266,6 +266,8 @@ int gs_profile_enable(int on);
 int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
 int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
 
+/* process-wide tuning switch for experiments and A/B measurements (e.g. "xcd_map": 0 / 1); no effect on results */
+int gs_tuning(const char* name, int value);
 const char* gs_status_string(int code);
 int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */
 const char* gs_last_stage(void); /* name of the stage that failed (debug mode names every kernel) */
