@@ -1,84 +1,55 @@
-// binning.hip -- tile binning: prefix sum of tiles touched, emission of the
-// (tile, Gaussian) pairs, tile ranges.  Replaces upstream InclusiveSum / duplicateWithKeys /
-// identifyTileRanges.
+// binning.hip -- tile binning: numbering of the (tile, Gaussian) pairs, the per-tile
+// depth-ordered Gaussian lists and the tile ranges.  Replaces upstream InclusiveSum / duplicateWithKeys /
+// cub::DeviceRadixSort over 64-bit keys / identifyTileRanges.
 //
-// MI355X-first formulation of the reference's "stable sort of (tile << 32 | depth_bits) keys": the
-// Gaussians are first put in (depth, index) order (a stable 32-bit sort over P items), the pairs are
-// then emitted Gaussian-major IN THAT ORDER, and a stable sort on the tile id alone (12-16 bits
-// over D items) yields exactly the list a stable 64-bit sort of the upstream keys yields -- with a
-// third of the bytes per pass and a third of the passes over the D-sized arrays.
+// MI355X-first formulation of the reference's "stable sort of (tile << 32 | depth_bits) keys".  The Gaussians are
+// first put in (depth, index) order (a stable 32-bit sort over P items, radix_sort.hip).  The list of tile t is then
+// simply the sub-sequence of that ranking whose tile rectangles cover t -- no pair is ever sorted.  The tile grid is cut
+// into BLOCKS of 64 x 4 tiles and the ranking into SEGMENTS; workgroup (block, segment) streams its segment, keeps the
+// Gaussians whose rectangle meets its block (ballot compaction, rank order preserved) and, per batch of up to 1024 of
+// them, builds in LDS one bit per (tile, Gaussian) pair: bit m of tile t's bitmap = "Gaussian m of the batch covers t".
+// The position of a pair in its tile's list is then a popcount prefix.  Two passes of the same kernel: pass 1 stores
+// the per-(segment, tile) pair counts; a small kernel turns them into prefixes over the segments and per-tile totals;
+// one workgroup scans the totals into the tile ranges (and orders the tiles by work for the render launch); pass 2
+// writes every pair's Gaussian index straight to its final slot.  Five launches and ~8 bytes moved per pair, where the
+// pair sort took ten launches and four passes over 8-byte pairs; the result is bit for bit the list a stable sort of
+// the upstream keys yields.
 #include "common.h"
 
-#define SC_THREADS 256
-#define SC_PER_THREAD (SCAN_ITEMS / SC_THREADS)
-
-// pass 1: gather tiles_touched into depth-rank order and reduce per block
-__global__ __launch_bounds__(SC_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                                 const uint32_t* __restrict__ tiles,
-                                                                 uint32_t* __restrict__ tt_rank,
-                                                                 uint32_t* __restrict__ bsum, int P) {
-    __shared__ uint32_t ws[4];
-    const int tid = threadIdx.x;
-    const int base = blockIdx.x * SCAN_ITEMS;
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SC_PER_THREAD; k++) {
-        const int r = base + k * SC_THREADS + tid;
-        if (r < P) {
-            const uint32_t t = tiles[sorted_idx[r]];
-            tt_rank[r] = t;
-            sum += t;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if ((tid & 63) == 0) ws[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// pass 2: per-block exclusive scan; every block adds up the sums of the blocks before it itself (they
-// are few: P / 4096), the last block also publishes the grand total = the pair count
-__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ tt_rank,
-                                                                const uint32_t* __restrict__ bsum,
-                                                                uint32_t* __restrict__ offs, int P,
-                                                                unsigned long long* __restrict__ count,
-                                                                unsigned long long* host_count) {
-    __shared__ uint32_t ws[4];
+// ---------------------------------------------------------------------------------------------------------------
+// Pair numbering.  Pair slots (the backward's gradient rows) are numbered Gaussian-major in INDEX order: Gaussian i owns
+// [first_pair[i], first_pair[i] + tiles_touched[i]).  first_pair = exclusive prefix sum of tiles_touched, whose first
+// level (one sum per 64-Gaussian wave) the preprocess kernel has already produced; the grand total is the frame's pair
+// count (num_rendered), stored in the geom state and straight into the caller's pinned host word.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_pair_kernel(const uint32_t* __restrict__ tiles,
+                                                         const uint32_t* __restrict__ wave_tiles, float* __restrict__ rec,
+                                                         int P, unsigned long long* __restrict__ count,
+                                                         unsigned long long* host_count) {
     __shared__ unsigned long long wb[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    unsigned long long before = 0;  // 64-bit: overflow of the 32-bit index space stays detectable in the count
-    for (int b = tid; b < (int)blockIdx.x; b += SC_THREADS) before += bsum[b];
+    const int w0 = 4 * (int)blockIdx.x;  // first preprocess wave of this workgroup's 256 Gaussians
+    unsigned long long before = 0;       // 64-bit: overflow of the 32-bit index space stays detectable in the count
+    for (int w = tid; w < w0; w += 256) before += wave_tiles[w];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
     if (lane == 0) wb[wid] = before;
-    const int base = blockIdx.x * SCAN_ITEMS + tid * SC_PER_THREAD;  // consecutive items per thread
-    uint32_t v[SC_PER_THREAD];
-    uint32_t tsum = 0;
-#pragma unroll
-    for (int k = 0; k < SC_PER_THREAD; k++) {
-        v[k] = (base + k < P) ? tt_rank[base + k] : 0u;
-        tsum += v[k];
-    }
-    uint32_t x = tsum;
+    const int i = blockIdx.x * 256 + tid;
+    const uint32_t v = i < P ? tiles[i] : 0u;
+    uint32_t x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d, 64);
+        const uint32_t y = __shfl_up(x, d, 64);
         if (lane >= d) x += y;
     }
-    if (lane == 63) ws[wid] = x;
     __syncthreads();
     const unsigned long long block_base = (wb[0] + wb[1]) + (wb[2] + wb[3]);
     uint32_t woff = 0;
-    for (int w = 0; w < wid; w++) woff += ws[w];
-    uint32_t excl = (uint32_t)block_base + woff + x - tsum;
-#pragma unroll
-    for (int k = 0; k < SC_PER_THREAD; k++) {
-        if (base + k < P) offs[base + k] = excl;
-        excl += v[k];
-    }
+    for (int w = 0; w < wid; w++) woff += wave_tiles[w0 + w];
+    if (i < P) rec[(size_t)i * REC_F + 9] = __uint_as_float((uint32_t)block_base + woff + x - v);
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-        const unsigned long long total = block_base + ws[0] + ws[1] + ws[2] + ws[3];
+        const unsigned long long total =
+            block_base + wave_tiles[w0] + wave_tiles[w0 + 1] + wave_tiles[w0 + 2] + wave_tiles[w0 + 3];
         count[0] = total;
         // ... and straight into the caller's pinned host word, which the host is polling: the pair count
         // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
@@ -86,135 +57,216 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* 
     }
 }
 
-int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
-                      uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
-                      hipStream_t s) {
-    const int nblk = (P + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, sorted_idx, tiles, tt_rank, bsum, P);
-    GS_LAUNCH_CHECK("scan.reduce", debug, s);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SC_THREADS), 0, s, tt_rank, bsum, offs, P, count, host_count);
-    GS_LAUNCH_CHECK("scan.apply", debug, s);
+int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* rec, unsigned long long* count,
+                      unsigned long long* host_count, int P, int debug, hipStream_t s) {
+    hipLaunchKernelGGL(first_pair_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tiles, wave_tiles, rec, P, count,
+                       host_count);
+    GS_LAUNCH_CHECK("first_pair", debug, s);
     return GS_OK;
 }
 
-// Emission of the (tile id, Gaussian index) pairs in depth-rank order, tiles y-outer / x-inner
-// (the upstream duplicateWithKeys order).  Also records each Gaussian's first pair index in its
-// splat record (slot 9): the backward pass addresses its per-pair gradient rows through it.
-//
-// Partitioned by OUTPUT, not by Gaussian: the nearest Gaussians come first in depth order and cover
-// hundreds of tiles each, so a wave that owns 64 consecutive ranks can have 100x the pairs of
-// another.  A workgroup owns EMIT_CHUNK consecutive pairs; emit_owner_kernel has recorded which rank
-// owns the first pair of every chunk, so the group stages the (at most EMIT_CHUNK + 1) ranks that
-// overlap its chunk in LDS and every pair finds its owner with a binary search over their offsets.
-// Stores are fully coalesced.
-__global__ __launch_bounds__(256) void emit_owner_kernel(const uint32_t* __restrict__ tt_rank,
-                                                         const uint32_t* __restrict__ offs, int P, const PairCount pc,
-                                                         uint32_t* __restrict__ owner, ZeroJob zero_a,
-                                                         ZeroJob zero_b) {
-    zero_job(zero_a);  // the tile sort's digit totals and the tile ranges (saves two fill launches)
-    zero_job(zero_b);
-    const uint32_t D = pair_count(pc);
-    const uint32_t nchunks = (D + EMIT_CHUNK - 1) / EMIT_CHUNK;
+// The Gaussians in depth-rank order with what binning needs of each: (index, rect min x | y << 16, rect size w | h << 16,
+// tiles touched) -- 16 bytes streamed by the binning workgroups instead of a 48-byte record gathered per rank.
+__global__ __launch_bounds__(256) void rank_list_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                        const float4* __restrict__ rec, const uint32_t* __restrict__ tiles,
+                                                        uint4* __restrict__ ranklist, int P) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P || D == 0) return;
-    const uint32_t tt = tt_rank[r];
-    if (!tt) return;
-    const uint32_t off = offs[r], last = off + tt - 1;
-    for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; c <= last / EMIT_CHUNK; c++) owner[c] = (uint32_t)r;
-    if (last == D - 1) owner[nchunks] = (uint32_t)r;  // the rank that owns the last pair
+    if (r >= P) return;
+    const uint32_t id = sorted_idx[r];
+    const float4 c = rec[(size_t)id * 3 + 2];
+    ranklist[r] = make_uint4(id, __float_as_uint(c.z), __float_as_uint(c.w), tiles[id]);
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                   const uint32_t* __restrict__ offs,
-                                                   const uint32_t* __restrict__ owner, float* __restrict__ rec,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                   const PairCount pc, int gx) {
-    __shared__ uint32_t s_off[EMIT_CHUNK + 1], s_idx[EMIT_CHUNK + 1], s_rmin[EMIT_CHUNK + 1], s_rsz[EMIT_CHUNK + 1];
-    const uint32_t D = pair_count(pc);
-    const uint32_t nchunks = (D + EMIT_CHUNK - 1) / EMIT_CHUNK;
-    const uint32_t c = blockIdx.x;
-    if (c >= nchunks) return;  // the grid covers the capacity
-    const uint32_t o0 = c * EMIT_CHUNK, o1 = min(D, o0 + EMIT_CHUNK);
-    const uint32_t r0 = owner[c], r1 = owner[c + 1 < nchunks ? c + 1 : nchunks];
-    // every rank in [r0, r1] has at least one pair (Gaussians without tiles sort behind all others), so
-    // they are at most EMIT_CHUNK + 1
-    const int cnt = (int)min(r1 - r0 + 1, (uint32_t)(EMIT_CHUNK + 1));
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const uint32_t off = offs[r0 + i], idx = sorted_idx[r0 + i];
-        float* R = rec + (size_t)idx * REC_F;
-        s_off[i] = off;
-        s_idx[i] = idx;
-        s_rmin[i] = __float_as_uint(R[10]);
-        s_rsz[i] = __float_as_uint(R[11]);
-        if (off >= o0) R[9] = __uint_as_float(off);  // the chunk in which the rank starts records its offset
+int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist, int P, int debug,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(rank_list_kernel, dim3((P + 255) / 256), dim3(256), 0, s, sorted_idx,
+                       reinterpret_cast<const float4*>(rec), tiles, ranklist, P);
+    GS_LAUNCH_CHECK("rank_list", debug, s);
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile lists.  Workgroup (block b of 64 x 4 tiles, segment g of the ranking), 1024 threads.
+// ---------------------------------------------------------------------------------------------------------------
+#define TBK_THREADS 1024
+#define TBK_BATCH 1024  // Gaussians per bitmap batch (32 words per tile)
+#define TBK_BUF 2048    // compacted Gaussians waiting for a batch (< 1024 carried + <= 1024 from one filter round)
+
+// a match's rectangle clipped to the block, in block-local tile coordinates: lx (6 bits) | ly (2) | w - 1 (6) | h - 1 (2)
+__device__ __forceinline__ uint32_t pack_local_rect(int lx, int ly, int lw, int lh) {
+    return (uint32_t)lx | ((uint32_t)ly << 6) | ((uint32_t)(lw - 1) << 8) | ((uint32_t)(lh - 1) << 14);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
+                                                               int nbx, int nblocks, int seg_len, int ntiles,
+                                                               uint32_t* __restrict__ seg_cnt,
+                                                               const uint2* __restrict__ ranges,
+                                                               uint32_t* __restrict__ point_list, const PairCount pc) {
+    __shared__ uint32_t m_id[TBK_BUF], m_rc[TBK_BUF];
+    __shared__ uint32_t m_off[TBK_BATCH + 1];
+    __shared__ uint32_t bitmap[32 * TB_TILES];  // [word][local tile]: the lanes of one Gaussian's tiles hit consecutive banks
+    __shared__ uint32_t run[TB_TILES], base[TB_TILES];
+    __shared__ uint32_t wcnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
+    const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
+    const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
+    if (WRITE) {
+        if (*pc.dev > (unsigned long long)pc.cap) return;  // the list would not fit the state it was carved for: the host
+                                                           // sees the count and runs the phase again (workgroup-uniform)
     }
+    if (tid < TB_TILES) {
+        run[tid] = 0u;
+        if (WRITE) {
+            const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
+            base[tid] = (tx < bx1 && ty < by1) ? ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx] : 0u;
+        }
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
+    int count = 0;  // compacted Gaussians in the buffer (workgroup-uniform)
     __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < EMIT_CHUNK / 256; k++) {
-        const uint32_t o = o0 + k * 256 + threadIdx.x;
-        if (o >= o1) break;
-        // owner: the largest i with s_off[i] <= o
-        int lo = 0, hi = cnt - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= o) lo = mid; else hi = mid - 1;
+
+    // one bitmap batch over the first n buffered Gaussians
+    auto process_batch = [&](const int n) {
+        const int nw = (n + 31) >> 5;
+        if (WRITE)
+            for (int k = tid; k < nw * TB_TILES; k += TBK_THREADS) bitmap[k] = 0u;
+        // exclusive prefix of the rectangles' areas: output o (one per pair) belongs to the Gaussian m with
+        // m_off[m] <= o < m_off[m + 1]
+        uint32_t area = 0;
+        if (tid < n) {
+            const uint32_t rc = m_rc[tid];
+            area = (((rc >> 8) & 63u) + 1u) * (((rc >> 14) & 3u) + 1u);
         }
-        const uint32_t o_off = s_off[lo], o_rmin = s_rmin[lo], o_rsz = s_rsz[lo];
-        const uint32_t w = o_rsz & 0xFFFFu;
-        const uint32_t li = o - o_off;
-        uint32_t y = (uint32_t)(((float)li + 0.5f) / (float)w);
-        if (y * w > li) y--;
-        if ((y + 1) * w <= li) y++;
-        const uint32_t x = li - y * w;
-        keys[o] = ((o_rmin >> 16) + y) * (uint32_t)gx + (o_rmin & 0xFFFFu) + x;
-        vals[o] = s_idx[lo];
-    }
-}
+        uint32_t x = area;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wcnt[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wcnt[w];
+        if (tid < n) m_off[tid] = woff + x - area;
+        if (tid == n - 1) m_off[n] = woff + x;
+        __syncthreads();
+        const uint32_t T = m_off[n];
+        // (Gaussian of the batch, local tile) of output o
+        auto locate = [&](const uint32_t o, int& m, int& lt) {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (m_off[mid] <= o) lo = mid; else hi = mid - 1;
+            }
+            m = lo;
+            const uint32_t rc = m_rc[lo];
+            const uint32_t j = o - m_off[lo], lw = ((rc >> 8) & 63u) + 1u;
+            const uint32_t dy = (j >= lw ? 1u : 0u) + (j >= 2u * lw ? 1u : 0u) + (j >= 3u * lw ? 1u : 0u);
+            lt = (int)((((rc >> 6) & 3u) + dy) * TB_W + (rc & 63u) + (j - dy * lw));
+        };
+        if (!WRITE) {
+            // counting pass: only how many pairs each tile gets
+            for (uint32_t o = tid; o < T; o += TBK_THREADS) {
+                int m, lt;
+                locate(o, m, lt);
+                atomicAdd(&run[lt], 1u);
+            }
+            __syncthreads();
+            return;
+        }
+        for (uint32_t o = tid; o < T; o += TBK_THREADS) {
+            int m, lt;
+            locate(o, m, lt);
+            atomicOr(&bitmap[(m >> 5) * TB_TILES + lt], 1u << (m & 31));
+        }
+        __syncthreads();
+        if (WRITE) {
+            // position of a pair in its tile's list: pairs of earlier segments and batches (base + run), then the
+            // Gaussians of this batch that come before it in the ranking and cover the tile too (popcount prefix)
+            for (uint32_t o = tid; o < T; o += TBK_THREADS) {
+                int m, lt;
+                locate(o, m, lt);
+                uint32_t rank = __popc(bitmap[(m >> 5) * TB_TILES + lt] & ((1u << (m & 31)) - 1u));
+                for (int w = 0; w < (m >> 5); w++) rank += __popc(bitmap[w * TB_TILES + lt]);
+                point_list[base[lt] + run[lt] + rank] = m_id[m];
+            }
+            __syncthreads();
+        }
+        if (tid < TB_TILES) {
+            uint32_t c = 0;
+            for (int w = 0; w < nw; w++) c += __popc(bitmap[w * TB_TILES + tid]);
+            run[tid] += c;
+        }
+        __syncthreads();
+    };
 
-int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, PairCount pc, int gx, int debug,
-                hipStream_t s) {
-    if (pc.cap == 0) return GS_OK;
-    const uint32_t nchunks = (uint32_t)(((uint64_t)pc.cap + EMIT_CHUNK - 1) / EMIT_CHUNK);
-    hipLaunchKernelGGL(emit_owner_kernel, dim3((P + 255) / 256), dim3(256), 0, s, tt_rank, offs, P, pc, owner, zero_a,
-                       zero_b);
-    GS_LAUNCH_CHECK("emit.owner", debug, s);
-    hipLaunchKernelGGL(emit_kernel, dim3(nchunks), dim3(256), 0, s, sorted_idx, offs, owner, rec, keys, vals, pc, gx);
-    GS_LAUNCH_CHECK("emit", debug, s);
-    return GS_OK;
-}
-
-// ranges[tile] = [first, end) in the sorted list (upstream identifyTileRanges); ranges pre-zeroed.
-__global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ tile_sorted,
-                                                     uint32_t* __restrict__ ranges, const PairCount pc) {
-    const int64_t D = (int64_t)pair_count(pc);
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D) return;
-    const uint32_t cur = tile_sorted[j];
-    if (j == 0) {
-        ranges[2 * cur] = 0;
-    } else {
-        const uint32_t prev = tile_sorted[j - 1];
-        if (cur != prev) {
-            ranges[2 * prev + 1] = (uint32_t)j;
-            ranges[2 * cur] = (uint32_t)j;
+    for (int rb = r0; rb < r1 || count > 0;) {
+        if (rb < r1) {
+            // filter round: 1024 ranks, those whose rectangle meets the block are appended in rank order
+            const int r = rb + tid;
+            bool hit = false;
+            uint32_t id = 0, rc = 0;
+            if (r < r1) {
+                const uint4 e = ranklist[r];
+                const int x0 = (int)(e.y & 0xFFFFu), y0 = (int)(e.y >> 16);
+                const int x1 = x0 + (int)(e.z & 0xFFFFu), y1 = y0 + (int)(e.z >> 16);
+                const int cx0 = max(x0, bx0), cx1 = min(x1, bx1), cy0 = max(y0, by0), cy1 = min(y1, by1);
+                hit = e.w != 0u && cx1 > cx0 && cy1 > cy0;
+                id = e.x;
+                if (hit) rc = pack_local_rect(cx0 - bx0, cy0 - by0, cx1 - cx0, cy1 - cy0);
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wcnt[wid] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t woff = 0, tot = 0;
+            for (int w = 0; w < 16; w++) {
+                const uint32_t c = wcnt[w];
+                woff += w < wid ? c : 0u;
+                tot += c;
+            }
+            if (hit) {
+                const int slot = count + (int)woff + __popcll(bal & lt_mask);
+                m_id[slot] = id;
+                m_rc[slot] = rc;
+            }
+            count += (int)tot;
+            rb += TBK_THREADS;
+            __syncthreads();
+        }
+        const bool last = rb >= r1;
+        while (count >= TBK_BATCH || (last && count > 0)) {
+            const int n = min(count, TBK_BATCH);
+            process_batch(n);
+            const int rem = count - n;  // < 1024: one element per thread moves to the front
+            uint32_t cid = 0, crc = 0;
+            if (tid < rem) { cid = m_id[n + tid]; crc = m_rc[n + tid]; }
+            __syncthreads();
+            if (tid < rem) { m_id[tid] = cid; m_rc[tid] = crc; }
+            count = rem;
+            __syncthreads();
         }
     }
-    if (j == D - 1) ranges[2 * cur + 1] = (uint32_t)D;
+    if (!WRITE && tid < TB_TILES) {
+        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
+        if (tx < bx1 && ty < by1) seg_cnt[(size_t)sg * ntiles + ty * gx + tx] = run[tid];
+    }
 }
 
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, PairCount pc, int ntiles, bool ranges_zeroed, int debug,
-                  hipStream_t s) {
-    if (!ranges_zeroed) {
-        hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
-        if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+// per tile: pair counts of the segments -> exclusive prefix over the segments (in place) and the tile's total
+__global__ __launch_bounds__(256) void seg_prefix_kernel(uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ tile_tot,
+                                                         int ntiles, int nseg) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t acc = 0;
+    for (int g = 0; g < nseg; g++) {
+        const uint32_t v = seg_cnt[(size_t)g * ntiles + t];
+        seg_cnt[(size_t)g * ntiles + t] = acc;
+        acc += v;
     }
-    if (pc.cap > 0) {
-        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)(((uint64_t)pc.cap + 255) / 256)), dim3(256), 0, s, tile_sorted,
-                           ranges, pc);
-        GS_LAUNCH_CHECK("ranges", debug, s);
-    }
-    return GS_OK;
+    tile_tot[t] = acc;
 }
 
 // Launch order of the per-tile render waves: tiles sorted by DESCENDING work estimate (a counting
@@ -226,14 +278,18 @@ int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, PairCount pc, i
 // per-quadrant last contributor).
 __device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
                                               int t) {
+    if (mode == 2) return keys[t];
     return mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
 }
+// mode 2: work = keys[tile] = the tile's pair count (seg_prefix_kernel); the kernel then FIRST writes the tile ranges
+// (exclusive prefix sum of the counts: upstream identifyTileRanges) into `ranges_out`.
 // HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the inputs are loaded once, all
 // loads in flight together (ntiles <= 32 * 1024); otherwise the three phases re-read them.
 template <bool HELD>
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ keys, int mode, int ntiles,
-                                                          uint32_t* __restrict__ order, const FillJob fill) {
+                                                          uint32_t* __restrict__ order, uint2* __restrict__ ranges_out,
+                                                          const PairCount pc, const FillJob fill) {
     if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
@@ -244,8 +300,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wmax[16];
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     hist[tid] = 0;
+    if (tid == 0) carry_s = 0;
     uint32_t held[HELD ? PER : 1];
     uint32_t mx = 0;
     if (HELD) {
@@ -258,6 +316,45 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
         }
     } else {
         for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
+    }
+    if (mode == 2) {
+        // tile ranges: exclusive scan of the counts in tile order, 1024 tiles per trip.  If the frame's pair count does
+        // not fit the state the lists were carved for, every range is left empty: the render that follows then draws an
+        // empty frame and touches nothing out of bounds (the host runs the phase again with a larger state).
+        const bool fits = *pc.dev <= (unsigned long long)pc.cap;
+        __syncthreads();
+        for (int i0 = 0; i0 < ntiles; i0 += 1024) {
+            const int t = i0 + tid;
+            uint32_t v;
+            if (HELD) {
+                v = 0;
+#pragma unroll
+                for (int i = 0; i < PER; i++)
+                    if (i * 1024 == i0) v = held[i];
+            } else {
+                v = t < ntiles ? keys[t] : 0u;
+            }
+            if (!fits) v = 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) wsum[wid] = x;
+            __syncthreads();
+            uint32_t woff = 0, tot = 0;
+            for (int w = 0; w < 16; w++) {
+                const uint32_t c = wsum[w];
+                woff += w < wid ? c : 0u;
+                tot += c;
+            }
+            const uint32_t first = carry_s + woff + x - v;
+            if (t < ntiles) ranges_out[t] = make_uint2(first, first + v);
+            __syncthreads();
+            if (tid == 0) carry_s += tot;
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
@@ -304,17 +401,44 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     }
 }
 
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, FillJob fill,
-                      int debug, hipStream_t s) {
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, uint32_t* ranges_out,
+                      PairCount pc, FillJob fill, int debug, hipStream_t s) {
     // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
     const size_t pieces = (fill.quads + 1023) / 1024;
     const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), pc, fill);
     else
         hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), pc, fill);
     GS_LAUNCH_CHECK("tile_order", debug, s);
+    return GS_OK;
+}
+
+// The whole tile binning of one frame: counting pass, prefixes, ranges + launch order, writing pass.
+int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, uint32_t* seg_cnt, uint32_t* tile_tot, uint32_t* ranges,
+                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
+    const BinGrid G = bin_grid(gx, gy);
+    const int nseg = bin_segments(G, P);
+    const int seg_len = (((P + nseg - 1) / nseg) + TBK_THREADS - 1) / TBK_THREADS * TBK_THREADS;
+    const int ntiles = gx * gy;
+    const dim3 grid((unsigned)(G.nblocks * nseg));
+    { StageScope sc_("tile_count", s);
+    hipLaunchKernelGGL(tile_bin_kernel<false>, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
+                       ntiles, seg_cnt, (const uint2*)nullptr, (uint32_t*)nullptr, pc);
+    GS_LAUNCH_CHECK("tile_count", debug, s); }
+    { StageScope sc_("seg_prefix", s);
+    hipLaunchKernelGGL(seg_prefix_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, seg_cnt, tile_tot, ntiles, nseg);
+    GS_LAUNCH_CHECK("seg_prefix", debug, s); }
+    { StageScope sc_("ranges_order", s);
+    const int rc = launch_tile_order(nullptr, tile_tot, 2, ntiles, order, ranges, pc, FillJob{nullptr, 0}, debug, s);
+    if (rc != GS_OK) return rc; }
+    if (pc.cap > 0) {
+        StageScope sc_("tile_write", s);
+        hipLaunchKernelGGL(tile_bin_kernel<true>, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
+                           ntiles, seg_cnt, reinterpret_cast<const uint2*>(ranges), point_list, pc);
+        GS_LAUNCH_CHECK("tile_write", debug, s);
+    }
     return GS_OK;
 }

@@ -131,16 +131,22 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         sort_totals_region((uint32_t*)(g + L.hist), a->P, 32, &zt.ptr, &zt.words);
         { StageScope sc_("preprocess", s);
         rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
-                               (uint32_t*)(g + L.clamped), k0, v0, radii, zt, s); }
+                               (uint32_t*)(g + L.clamped), k0, v0, radii, (uint32_t*)(g + L.wsum), zt, s); }
+        if (rc != GS_OK) return rc;
+        // pair numbering (Gaussian-major, index order) and the pair count: needs nothing of the depth sort, so the
+        // count is on its way to the host while the sort runs
+        { StageScope sc_("pair_scan", s);
+        rc = launch_first_pair((const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
+                               a->P, a->debug, s); }
         if (rc != GS_OK) return rc;
         // stable sort by depth bits: ties keep ascending Gaussian index (the reference's tie order)
         { StageScope sc_("depth_sort", s);
         rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s); }
         if (rc != GS_OK) return rc;
         // 4 passes -> the sorted index ends in (k0, v0)
-        { StageScope sc_("scan", s);
-        rc = launch_scan_tiles(v0, (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.tt_rank), (uint32_t*)(g + L.offs),
-                               (uint32_t*)(g + L.bsum), count, poll, a->P, a->debug, s); }
+        { StageScope sc_("rank_list", s);
+        rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist), a->P,
+                              a->debug, s); }
         if (rc != GS_OK) return rc;
     }
     if (count_host_pinned && (!poll || a->P == 0)) {
@@ -175,36 +181,21 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     const uint32_t* point_list = nullptr;
     const unsigned long long* count_dev = (const unsigned long long*)(g + L.count);
     const PairCount pc{count_dev, (uint32_t)cap};
+    (void)ntiles;
     int rc;
-    if (cap > 0) {
-        uint32_t* k0 = (uint32_t*)(b + B.key0);
-        uint32_t* k1 = (uint32_t*)(b + B.key1);
-        uint32_t* v0 = (uint32_t*)(b + B.val0);
-        uint32_t* v1 = (uint32_t*)(b + B.val1);
-        const int bits = tile_bits(ntiles);
-        ZeroJob zt, zr;  // the tile sort's digit totals and the tile ranges, cleared by the emission pre-pass
-        sort_totals_region((uint32_t*)(b + B.hist), cap, bits, &zt.ptr, &zt.words);
-        zr.ptr = ranges;
-        zr.words = ntiles * 2;
-        { StageScope sc_("emit", s);
-        rc = launch_emit((const uint32_t*)(g + L.val0), (const uint32_t*)(g + L.tt_rank), (const uint32_t*)(g + L.offs),
-                         (float*)(g + L.rec), k0, v0, (uint32_t*)(b + B.owner), zt, zr, a->P, pc, I.gx, a->debug, s); }
-        if (rc != GS_OK) return rc;
-        { StageScope sc_("tile_sort", s);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(b + B.hist), cap, bits, true, a->debug, s, count_dev); }
-        if (rc != GS_OK) return rc;
-        const bool odd = radix_passes(bits) & 1;
-        point_list = odd ? v1 : v0;
-        { StageScope sc_("ranges", s);
-        rc = launch_ranges(odd ? k1 : k0, ranges, pc, ntiles, true, a->debug, s); }
+    if (a->P > 0) {
+        point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
+        rc = launch_tile_lists((const uint4*)(g + L.ranklist), a->P, I.gx, I.gy, (uint32_t*)(im + I.seg_cnt),
+                               (uint32_t*)(im + I.tile_tot), ranges, (uint32_t*)(im + I.order),
+                               cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+        StageScope sc_("ranges_order", s);
+        rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), nullptr, pc, FillJob{nullptr, 0}, a->debug, s);
+        if (rc != GS_OK) return rc;
     }
-    { StageScope sc_("tile_order", s);
-    rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), FillJob{nullptr, 0}, a->debug, s); }
-    if (rc != GS_OK) return rc;
     QuadLists ql;
     ql.qlist = cap > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
@@ -306,8 +297,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     hipError_t e = hipMemcpyAsync(im + I.ranges, is + I.ranges, (size_t)ntiles * 8, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(im + I.order, is + I.order, (size_t)ntiles * 4, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) { gs_set_error((int)e, "shared.copy"); return GS_E_HIP; }
-    const bool odd = radix_passes(tile_bits(ntiles)) & 1;
-    const uint32_t* point_list = D > 0 ? (const uint32_t*)(b + (odd ? B.val1 : B.val0)) : nullptr;
+    const uint32_t* point_list = D > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
     QuadLists ql;
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // rewritten with identical content (same geometry)
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
@@ -366,8 +356,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b,
-                               FillJob{reinterpret_cast<uint4*>(q8), (size_t)D}, a->debug, s); }
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr,
+                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D}, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
@@ -538,12 +528,10 @@ int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {
 int gs_binning_field(void* binning, int64_t D, int32_t W, int32_t H, int32_t field, void** out) {
     if (!binning || !out || D < 0) return GS_E_BAD_ARG;
     const BinLayout B = bin_layout(D);
-    const ImgLayout I = img_layout(W, H);
-    const bool odd = radix_passes(tile_bits(I.gx * I.gy)) & 1;
+    (void)W; (void)H;
     char* b = (char*)binning;
     switch (field) {
-        case 0: *out = b + (odd ? B.val1 : B.val0); break;
-        case 1: *out = b + (odd ? B.key1 : B.key0); break;
+        case 0: *out = b + B.point_list; break;  // (the tile id of every entry follows from the image state's ranges)
         default: return GS_E_BAD_ARG;
     }
     return GS_OK;

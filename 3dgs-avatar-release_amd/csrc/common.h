@@ -27,8 +27,8 @@ static inline size_t sort_table_words(size_t n) {
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
 struct GeomLayout {
-    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, tt_rank, offs, bsum, hist, count, total;
-    int nblk_sort, nblk_scan;
+    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, wsum, hist, count, total;
+    int nblk_sort, nwaves;
 };
 static inline GeomLayout geom_layout(int P) {
     GeomLayout L;
@@ -36,7 +36,7 @@ static inline GeomLayout geom_layout(int P) {
     size_t n = (size_t)(P > 0 ? P : 1);
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     L.nblk_sort = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
-    L.nblk_scan = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
+    L.nwaves = (int)((n + 255) / 256) * 4;  // waves of the preprocess launch (256-thread workgroups)
     L.rec = take(n * REC_F * 4);
     L.depths = take(n * 4);
     L.tiles = take(n * 4);
@@ -45,9 +45,8 @@ static inline GeomLayout geom_layout(int P) {
     L.key1 = take(n * 4);
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
-    L.tt_rank = take(n * 4);
-    L.offs = take(n * 4);
-    L.bsum = take((size_t)(L.nblk_scan + 1) * 4);
+    L.ranklist = take(n * 16);               // (index, rect min, rect size, tiles touched) in depth-rank order
+    L.wsum = take((size_t)L.nwaves * 4);     // tiles touched per preprocess wave
     L.hist = take(sort_table_words(n) * 4);
     L.count = take(64);
     L.total = o;
@@ -55,29 +54,45 @@ static inline GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t key0, key1, val0, val1, hist, qlist, owner, total;
-    int nblk_sort;
+    size_t point_list, qlist, total;
 };
-#define EMIT_CHUNK 2048  // pairs emitted per workgroup
 static inline BinLayout bin_layout(int64_t D) {
     BinLayout L;
     size_t o = 0;
     size_t n = (size_t)(D > 0 ? D : 1);
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
-    L.nblk_sort = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
-    L.key0 = take(n * 4);
-    L.key1 = take(n * 4);
-    L.val0 = take(n * 4);
-    L.val1 = take(n * 4);
-    L.hist = take(sort_table_words(n) * 4);
-    L.qlist = take(n * 16);  // per quadrant: compacted Gaussian indices the forward visited
-    L.owner = take((n / EMIT_CHUNK + 3) * 4);  // rank owning the first pair of every emission chunk (+ the last pair)
+    L.point_list = take(n * 4);  // Gaussian indices, tile-major, (depth, index) order inside a tile
+    L.qlist = take(n * 16);      // per quadrant: compacted Gaussian indices the forward visited
     L.total = o;
     return L;
 }
 
+// Tile binning works on BLOCKS of TB_W x TB_H tiles (256 tiles: one workgroup holds a bitmap of them in LDS) and on
+// SEGMENTS of the depth-ranked Gaussian list; workgroup (block, segment) counts / writes the pairs of its segment's
+// Gaussians with its block's tiles (binning.hip).
+#define TB_W 64
+#define TB_H 4
+#define TB_TILES (TB_W * TB_H)
+#define TB_MAX_SEG 64
+struct BinGrid { int nbx, nby, nblocks, nseg_max; };
+static inline BinGrid bin_grid(int gx, int gy) {
+    BinGrid G;
+    G.nbx = (gx + TB_W - 1) / TB_W;
+    G.nby = (gy + TB_H - 1) / TB_H;
+    G.nblocks = G.nbx * G.nby;
+    int s = (512 + G.nblocks - 1) / G.nblocks;  // about two workgroups per CU over the chip
+    G.nseg_max = s < 1 ? 1 : (s > TB_MAX_SEG ? TB_MAX_SEG : s);
+    return G;
+}
+// segments actually used for P Gaussians: at least 1024 of them per segment
+static inline int bin_segments(const BinGrid& G, int P) {
+    int s = (P + 1023) / 1024;
+    if (s < 1) s = 1;
+    return s < G.nseg_max ? s : G.nseg_max;
+}
+
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, total;
     int gx, gy;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -86,22 +101,19 @@ static inline ImgLayout img_layout(int W, int H) {
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     L.gx = (W + TILE - 1) / TILE;
     L.gy = (H + TILE - 1) / TILE;
-    L.ranges = take((size_t)L.gx * L.gy * 8);
+    const size_t nt = (size_t)L.gx * L.gy;
+    L.ranges = take(nt * 8);
     L.n_contrib = take((size_t)W * H * 4);
     L.final_T = take((size_t)W * H * 4);
     L.ncon_c = take((size_t)W * H * 4);            // per pixel: last contributor in its quadrant's COMPACTED list
-    L.tile_nmax = take((size_t)L.gx * L.gy * 16);  // per quadrant: compacted entries up to the last contributor
-    L.order = take((size_t)L.gx * L.gy * 4);
+    L.tile_nmax = take(nt * 16);                   // per quadrant: compacted entries up to the last contributor
+    L.order = take(nt * 4);
+    L.seg_cnt = take(nt * 4 * (size_t)bin_grid(L.gx, L.gy).nseg_max);  // [segment][tile] pair counts, then their prefix
+    L.tile_tot = take(nt * 4);                     // pairs per tile
     L.total = o;
     return L;
 }
 
-// number of key bits the tile sort must cover, and which of the ping-pong buffers ends up sorted
-static inline int tile_bits(int ntiles) {
-    int b = 1;
-    while ((1 << b) < ntiles) b++;
-    return b;
-}
 static inline int radix_passes(int bits) { return (bits + 7) / 8; }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,7 +176,8 @@ struct StageScope {
 // Stage launchers (each enqueues on `s`, returns GS_OK / GS_E_HIP)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, ZeroJob zero, hipStream_t s);
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, ZeroJob zero,
+                      hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
@@ -185,14 +198,15 @@ static inline void sort_totals_region(uint32_t* hist, int64_t n, int bits, uint3
 }
 
 
-int launch_scan_tiles(const uint32_t* sorted_idx, const uint32_t* tiles, uint32_t* tt_rank, uint32_t* offs,
-                      uint32_t* bsum, unsigned long long* count, unsigned long long* host_count, int P, int debug,
-                      hipStream_t s);
-int launch_emit(const uint32_t* sorted_idx, const uint32_t* tt_rank, const uint32_t* offs, float* rec, uint32_t* keys,
-                uint32_t* vals, uint32_t* owner, ZeroJob zero_a, ZeroJob zero_b, int P, PairCount pc, int gx, int debug,
-                hipStream_t s);
-int launch_ranges(const uint32_t* tile_sorted, uint32_t* ranges, PairCount pc, int ntiles, bool ranges_zeroed, int debug,
-                  hipStream_t s);
+// pair numbering: prefix sum of tiles touched in INDEX order -> every Gaussian's first pair (record slot 9) and the
+// frame's pair count (geom state + the caller's pinned host word)
+int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* rec, unsigned long long* count,
+                      unsigned long long* host_count, int P, int debug, hipStream_t s);
+// tile binning (binning.hip): rank list -> per-(segment, tile) counts -> ranges + launch order -> tile lists
+int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist, int P, int debug,
+                     hipStream_t s);
+int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, uint32_t* seg_cnt, uint32_t* tile_tot, uint32_t* ranges,
+                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)
 int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
@@ -228,8 +242,8 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
 // `fill`: 16-byte words the kernel's other workgroups set to all-ones while the first one orders the tiles (the
 // backward's ROW_UNWRITTEN marks: a fill launch less, and it overlaps the single-workgroup ordering)
 struct FillJob { uint4* ptr; size_t quads; };
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, FillJob fill,
-                      int debug, hipStream_t s);
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order,
+                      uint32_t* ranges_out, PairCount pc, FillJob fill, int debug, hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)

@@ -33,10 +33,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy, int tile_rect,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
-    uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii, ZeroJob zero) {
+    uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii,
+    uint32_t* __restrict__ wave_tiles, ZeroJob zero) {
     zero_job(zero);  // the depth sort's digit totals (saves a fill launch)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    // threads past the end (last workgroup only) redo Gaussian P - 1 and store nothing: every lane of every wave reaches
+    // the wave-level sum of tiles touched at the end
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = gi < P;
+    const int i = live ? gi : P - 1;
 
     float V[16], PV[16];
 #pragma unroll
@@ -121,21 +125,30 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             }
         }
     }
-    float4* R = reinterpret_cast<float4*>(rec) + (size_t)i * 3;
-    R[0] = r0;
-    R[1] = r1;
-    R[2] = make_float4(r2x, __uint_as_float(off_bits), __uint_as_float(rmin_bits), __uint_as_float(rsize_bits));
-    depths[i] = depth;
-    tiles[i] = tt;
-    clamped[i] = cl;
-    radii[i] = radius;
-    // depth-sort key: positive float bits are monotone as unsigned; culled Gaussians go last
-    sort_keys[i] = tt ? __float_as_uint(depth) : 0xFFFFFFFFu;
-    sort_vals[i] = (uint32_t)i;
+    if (live) {
+        float4* R = reinterpret_cast<float4*>(rec) + (size_t)i * 3;
+        R[0] = r0;
+        R[1] = r1;
+        R[2] = make_float4(r2x, __uint_as_float(off_bits), __uint_as_float(rmin_bits), __uint_as_float(rsize_bits));
+        depths[i] = depth;
+        tiles[i] = tt;
+        clamped[i] = cl;
+        radii[i] = radius;
+        // depth-sort key: positive float bits are monotone as unsigned; culled Gaussians go last
+        sort_keys[i] = tt ? __float_as_uint(depth) : 0xFFFFFFFFu;
+        sort_vals[i] = (uint32_t)i;
+    }
+    // tiles touched by this wave's 64 Gaussians: the first level of the prefix sum that numbers the (tile, Gaussian)
+    // pairs (first_pair_kernel), saving its reduction launch
+    uint32_t wsum = live ? tt : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_tiles[gi >> 6] = wsum;
 }
 
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, ZeroJob zero, hipStream_t s) {
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, ZeroJob zero,
+                      hipStream_t s) {
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
     const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
     const int blocks = (a.P + 255) / 256;
@@ -144,7 +157,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
                        a.tile_rect,
-                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, zero);
+                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, wave_tiles, zero);
     GS_LAUNCH_CHECK("preprocess", a.debug, s);
     return GS_OK;
 }

@@ -63,14 +63,22 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
         ) if P > 0 else {}
         b = dict(
             point_list=_view(binning, field(L.gs_binning_field, binning.data_ptr(), D, W, H, 0), 4 * D, np.uint32),
-            tile_ids=_view(binning, field(L.gs_binning_field, binning.data_ptr(), D, W, H, 1), 4 * D, np.uint32),
-        ) if D > 0 else dict(point_list=np.zeros(0, np.uint32), tile_ids=np.zeros(0, np.uint32))
+        ) if D > 0 else dict(point_list=np.zeros(0, np.uint32))
         im = dict(
             ranges=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 0), 8 * gx * gy, np.uint32).reshape(-1, 2),
             n_contrib=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 1), 4 * W * H, np.uint32).reshape(H, W),
             final_T=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 2), 4 * W * H, np.float32).reshape(H, W),
             qcount=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 3), 16 * gx * gy, np.uint32).reshape(-1, 4),
         )
+    # the tile of every list entry: the lists are stored tile after tile, so the ranges say it (upstream keeps the tile
+    # id in the high half of its sort keys)
+    r = im["ranges"].astype(np.int64)
+    lens = np.maximum(r[:, 1] - r[:, 0], 0)
+    nz = lens > 0
+    starts = r[nz, 0]
+    ok = int(lens.sum()) == D and (starts.size == 0 or (starts[0] == 0 and np.array_equal(starts[1:], r[nz, 1][:-1])))
+    # (consistent only if the non-empty ranges tile [0, D) in tile order; otherwise a pattern no comparison accepts)
+    b["tile_ids"] = np.repeat(np.arange(r.shape[0], dtype=np.uint32), lens) if ok else np.full(D, 0xFFFFFFFF, np.uint32)
     return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im)
 
 

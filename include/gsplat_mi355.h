@@ -247,9 +247,9 @@ int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, d
 
 /* ---- introspection for parity tests: device pointers INTO the opaque state buffers.  `field`:
  *  geom:    0 depths f32[P]        1 tiles_touched u32[P]   2 splat records f32[P,12]
- *           (x, y, conicA, conicB, conicC, opacity, r, g, b, dup_offset u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))
+ *           (x, y, conicA, conicB, conicC, opacity, r, g, b, first pair u32, rect_min u32 (x | y<<16), rect_size u32 (w | h<<16))
  *           3 clamped bitmask u32[P]   4 depth-sorted Gaussian index u32[P]   5 num_rendered u64[1]
- *  binning: 0 point_list u32[D] (sorted (tile, depth) order)   1 sorted tile ids u32[D]
+ *  binning: 0 point_list u32[D] (tile after tile, (depth, index) order inside a tile; tile t owns ranges[t] of it)
  *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W]
  *           3 per-quadrant compacted count up to the last contributor u32[tiles,4]
  *           4 per-pixel last contributor in compacted coordinates u32[H,W] */
