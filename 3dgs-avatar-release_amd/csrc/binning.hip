@@ -89,12 +89,24 @@ int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_
 // Tile lists.  Workgroup (block b of 64 x 4 tiles, segment g of the ranking), 1024 threads.
 // ---------------------------------------------------------------------------------------------------------------
 #define TBK_THREADS 1024
-#define TBK_BATCH 1024  // Gaussians per bitmap batch (32 words per tile)
-#define TBK_BUF 2048    // compacted Gaussians waiting for a batch (< 1024 carried + <= 1024 from one filter round)
+#define TBK_WAVES (TBK_THREADS / 64)
+#define TBK_BATCH 1024   // Gaussians per bitmap batch (32 words per tile)
+#define TBK_CHUNK 2048   // ranks filtered per trip (128 per wave)
+#define TBK_BUF (TBK_BATCH + TBK_CHUNK)  // compacted Gaussians waiting for a batch: < 1024 carried + <= 2048 new
 
 // a match's rectangle clipped to the block, in block-local tile coordinates: lx (6 bits) | ly (2) | w - 1 (6) | h - 1 (2)
 __device__ __forceinline__ uint32_t pack_local_rect(int lx, int ly, int lw, int lh) {
     return (uint32_t)lx | ((uint32_t)ly << 6) | ((uint32_t)(lw - 1) << 8) | ((uint32_t)(lh - 1) << 14);
+}
+
+// Does rank-list entry e meet the tile block [bx0, bx1) x [by0, by1)?  If so *rc = its clipped rectangle (packed).
+__device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int bx1, int by1, uint32_t* rc) {
+    const int x0 = (int)(e.y & 0xFFFFu), y0 = (int)(e.y >> 16);
+    const int x1 = x0 + (int)(e.z & 0xFFFFu), y1 = y0 + (int)(e.z >> 16);
+    const int cx0 = max(x0, bx0), cx1 = min(x1, bx1), cy0 = max(y0, by0), cy1 = min(y1, by1);
+    const bool hit = e.w != 0u && cx1 > cx0 && cy1 > cy0;
+    *rc = hit ? pack_local_rect(cx0 - bx0, cy0 - by0, cx1 - cx0, cy1 - cy0) : 0u;
+    return hit;
 }
 
 template <bool WRITE>
@@ -104,10 +116,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
                                                                const uint2* __restrict__ ranges,
                                                                uint32_t* __restrict__ point_list, const PairCount pc) {
     __shared__ uint32_t m_id[TBK_BUF], m_rc[TBK_BUF];
-    __shared__ uint32_t m_off[TBK_BATCH + 1];
-    __shared__ uint32_t bitmap[32 * TB_TILES];  // [word][local tile]: the lanes of one Gaussian's tiles hit consecutive banks
+    __shared__ uint32_t bitmap[WRITE ? 32 * TB_TILES : 1];         // [word][local tile]: a Gaussian's tiles hit consecutive banks
+    __shared__ unsigned short pre[WRITE ? 32 * TB_TILES : 1];     // pairs of the batch in the tile before word w
+    __shared__ unsigned short qtot[WRITE ? 4 * TB_TILES : 1];
     __shared__ uint32_t run[TB_TILES], base[TB_TILES];
-    __shared__ uint32_t wcnt[16];
+    __shared__ uint32_t wcnt[TBK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
@@ -128,123 +141,128 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
     int count = 0;  // compacted Gaussians in the buffer (workgroup-uniform)
     __syncthreads();
 
-    // one bitmap batch over the first n buffered Gaussians
-    auto process_batch = [&](const int n) {
-        const int nw = (n + 31) >> 5;
-        if (WRITE)
-            for (int k = tid; k < nw * TB_TILES; k += TBK_THREADS) bitmap[k] = 0u;
-        // exclusive prefix of the rectangles' areas: output o (one per pair) belongs to the Gaussian m with
-        // m_off[m] <= o < m_off[m + 1]
-        uint32_t area = 0;
-        if (tid < n) {
-            const uint32_t rc = m_rc[tid];
-            area = (((rc >> 8) & 63u) + 1u) * (((rc >> 14) & 3u) + 1u);
-        }
-        uint32_t x = area;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wcnt[wid] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wid; w++) woff += wcnt[w];
-        if (tid < n) m_off[tid] = woff + x - area;
-        if (tid == n - 1) m_off[n] = woff + x;
-        __syncthreads();
-        const uint32_t T = m_off[n];
-        // (Gaussian of the batch, local tile) of output o
-        auto locate = [&](const uint32_t o, int& m, int& lt) {
-            int lo = 0, hi = n - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (m_off[mid] <= o) lo = mid; else hi = mid - 1;
+    // Every match is handled by a group of 16 lanes (four matches per wave and trip): lane j of the group takes the
+    // tiles j, j + 16, ... of the match's clipped rectangle (the average rectangle has ~12 tiles in a block).
+    const int grp = lane >> 4, gl = lane & 15;
+    auto for_each_pair = [&](const int n, auto&& body) {
+        for (int m0 = wid * 4; m0 < n; m0 += TBK_WAVES * 4) {
+            const int m = m0 + grp;
+            if (m < n) {
+                const uint32_t rc = m_rc[m];
+                const uint32_t lw = ((rc >> 8) & 63u) + 1u, lh = ((rc >> 14) & 3u) + 1u;
+                const uint32_t area = lw * lh, lx = rc & 63u, ly = (rc >> 6) & 3u;
+                for (uint32_t j = (uint32_t)gl; j < area; j += 16u) {
+                    const uint32_t dy = (j >= lw ? 1u : 0u) + (j >= 2u * lw ? 1u : 0u) + (j >= 3u * lw ? 1u : 0u);
+                    body(m, (int)((ly + dy) * TB_W + lx + (j - dy * lw)));
+                }
             }
-            m = lo;
-            const uint32_t rc = m_rc[lo];
-            const uint32_t j = o - m_off[lo], lw = ((rc >> 8) & 63u) + 1u;
-            const uint32_t dy = (j >= lw ? 1u : 0u) + (j >= 2u * lw ? 1u : 0u) + (j >= 3u * lw ? 1u : 0u);
-            lt = (int)((((rc >> 6) & 3u) + dy) * TB_W + (rc & 63u) + (j - dy * lw));
-        };
+        }
+    };
+
+    // one batch over the first n buffered Gaussians
+    auto process_batch = [&](const int n) {
         if (!WRITE) {
             // counting pass: only how many pairs each tile gets
-            for (uint32_t o = tid; o < T; o += TBK_THREADS) {
-                int m, lt;
-                locate(o, m, lt);
-                atomicAdd(&run[lt], 1u);
-            }
+            for_each_pair(n, [&](int, int lt) { atomicAdd(&run[lt], 1u); });
             __syncthreads();
             return;
         }
-        for (uint32_t o = tid; o < T; o += TBK_THREADS) {
-            int m, lt;
-            locate(o, m, lt);
-            atomicOr(&bitmap[(m >> 5) * TB_TILES + lt], 1u << (m & 31));
+        const int nw = (n + 31) >> 5;
+        for (int k = tid; k < nw * TB_TILES; k += TBK_THREADS) bitmap[k] = 0u;
+        __syncthreads();
+        // bit m of tile lt's bitmap = "Gaussian m of the batch covers lt"
+        for_each_pair(n, [&](int m, int lt) { atomicOr(&bitmap[(m >> 5) * TB_TILES + lt], 1u << (m & 31)); });
+        __syncthreads();
+        // pre[w][lt] = pairs of tile lt in the words before w: thread (quarter q, tile lt) sums its 8 words, the quarters'
+        // totals are exchanged, then every thread writes the prefixes of its words
+        {
+            const int lt = tid & (TB_TILES - 1), q = tid >> 8;
+            uint32_t c[8], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int w = q * 8 + k;
+                c[k] = w < nw ? (uint32_t)__popc(bitmap[w * TB_TILES + lt]) : 0u;
+                tot += c[k];
+            }
+            qtot[q * TB_TILES + lt] = (unsigned short)tot;
+            __syncthreads();
+            uint32_t acc = 0;
+            for (int qq = 0; qq < q; qq++) acc += qtot[qq * TB_TILES + lt];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int w = q * 8 + k;
+                if (w < nw) pre[w * TB_TILES + lt] = (unsigned short)acc;
+                acc += c[k];
+            }
         }
         __syncthreads();
-        if (WRITE) {
-            // position of a pair in its tile's list: pairs of earlier segments and batches (base + run), then the
-            // Gaussians of this batch that come before it in the ranking and cover the tile too (popcount prefix)
-            for (uint32_t o = tid; o < T; o += TBK_THREADS) {
-                int m, lt;
-                locate(o, m, lt);
-                uint32_t rank = __popc(bitmap[(m >> 5) * TB_TILES + lt] & ((1u << (m & 31)) - 1u));
-                for (int w = 0; w < (m >> 5); w++) rank += __popc(bitmap[w * TB_TILES + lt]);
-                point_list[base[lt] + run[lt] + rank] = m_id[m];
-            }
-            __syncthreads();
-        }
+        // position of a pair in its tile's list: pairs of earlier segments and batches (base + run), then the
+        // Gaussians of this batch that come before it in the ranking and cover the tile too
+        for_each_pair(n, [&](int m, int lt) {
+            const int w = m >> 5;
+            const uint32_t rank = (uint32_t)pre[w * TB_TILES + lt] + __popc(bitmap[w * TB_TILES + lt] & ((1u << (m & 31)) - 1u));
+            point_list[base[lt] + run[lt] + rank] = m_id[m];
+        });
+        __syncthreads();
         if (tid < TB_TILES) {
             uint32_t c = 0;
-            for (int w = 0; w < nw; w++) c += __popc(bitmap[w * TB_TILES + tid]);
+            for (int q = 0; q < 4; q++) c += qtot[q * TB_TILES + tid];
             run[tid] += c;
         }
         __syncthreads();
     };
 
+    // Filter: wave w owns ranks [rb + 128 w, rb + 128 w + 128) of the trip, two per lane, so the compaction needs no
+    // workgroup barrier per 64 ranks: one barrier for the waves' counts, then every wave writes its matches (rank order)
+    // at its offset.  The next trip's entries are loaded before this trip's are processed.
+    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
+    auto load_trip = [&](const int rb) {
+        const int ra = rb + wid * 128 + lane, rbb = ra + 64;
+        e0 = ra < r1 ? ranklist[ra] : make_uint4(0, 0, 0, 0);   // (tiles touched = 0: never a match)
+        e1 = rbb < r1 ? ranklist[rbb] : make_uint4(0, 0, 0, 0);
+    };
+    if (r0 < r1) load_trip(r0);
     for (int rb = r0; rb < r1 || count > 0;) {
         if (rb < r1) {
-            // filter round: 1024 ranks, those whose rectangle meets the block are appended in rank order
-            const int r = rb + tid;
-            bool hit = false;
-            uint32_t id = 0, rc = 0;
-            if (r < r1) {
-                const uint4 e = ranklist[r];
-                const int x0 = (int)(e.y & 0xFFFFu), y0 = (int)(e.y >> 16);
-                const int x1 = x0 + (int)(e.z & 0xFFFFu), y1 = y0 + (int)(e.z >> 16);
-                const int cx0 = max(x0, bx0), cx1 = min(x1, bx1), cy0 = max(y0, by0), cy1 = min(y1, by1);
-                hit = e.w != 0u && cx1 > cx0 && cy1 > cy0;
-                id = e.x;
-                if (hit) rc = pack_local_rect(cx0 - bx0, cy0 - by0, cx1 - cx0, cy1 - cy0);
-            }
-            const unsigned long long bal = __ballot(hit);
-            if (lane == 0) wcnt[wid] = (uint32_t)__popcll(bal);
+            uint32_t rc0, rc1;
+            const bool h0 = block_hit(e0, bx0, by0, bx1, by1, &rc0), h1 = block_hit(e1, bx0, by0, bx1, by1, &rc1);
+            const uint32_t id0 = e0.x, id1 = e1.x;
+            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+            const int c0 = __popcll(b0), c1 = __popcll(b1);
+            if (lane == 0) wcnt[wid] = (uint32_t)(c0 + c1);
+            if (rb + TBK_CHUNK < r1) load_trip(rb + TBK_CHUNK);
             __syncthreads();
             uint32_t woff = 0, tot = 0;
-            for (int w = 0; w < 16; w++) {
+            for (int w = 0; w < TBK_WAVES; w++) {
                 const uint32_t c = wcnt[w];
                 woff += w < wid ? c : 0u;
                 tot += c;
             }
-            if (hit) {
-                const int slot = count + (int)woff + __popcll(bal & lt_mask);
-                m_id[slot] = id;
-                m_rc[slot] = rc;
+            if (h0) {
+                const int slot = count + (int)woff + __popcll(b0 & lt_mask);
+                m_id[slot] = id0;
+                m_rc[slot] = rc0;
+            }
+            if (h1) {
+                const int slot = count + (int)woff + c0 + __popcll(b1 & lt_mask);
+                m_id[slot] = id1;
+                m_rc[slot] = rc1;
             }
             count += (int)tot;
-            rb += TBK_THREADS;
+            rb += TBK_CHUNK;
             __syncthreads();
         }
         const bool last = rb >= r1;
         while (count >= TBK_BATCH || (last && count > 0)) {
             const int n = min(count, TBK_BATCH);
             process_batch(n);
-            const int rem = count - n;  // < 1024: one element per thread moves to the front
-            uint32_t cid = 0, crc = 0;
-            if (tid < rem) { cid = m_id[n + tid]; crc = m_rc[n + tid]; }
+            const int rem = count - n;  // < 2048: at most two elements per thread move to the front
+            uint32_t cid0 = 0, crc0 = 0, cid1 = 0, crc1 = 0;
+            if (tid < rem) { cid0 = m_id[n + tid]; crc0 = m_rc[n + tid]; }
+            if (tid + TBK_THREADS < rem) { cid1 = m_id[n + tid + TBK_THREADS]; crc1 = m_rc[n + tid + TBK_THREADS]; }
             __syncthreads();
-            if (tid < rem) { m_id[tid] = cid; m_rc[tid] = crc; }
+            if (tid < rem) { m_id[tid] = cid0; m_rc[tid] = crc0; }
+            if (tid + TBK_THREADS < rem) { m_id[tid + TBK_THREADS] = cid1; m_rc[tid + TBK_THREADS] = crc1; }
             count = rem;
             __syncthreads();
         }
@@ -255,18 +273,36 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
     }
 }
 
-// per tile: pair counts of the segments -> exclusive prefix over the segments (in place) and the tile's total
-__global__ __launch_bounds__(256) void seg_prefix_kernel(uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ tile_tot,
-                                                         int ntiles, int nseg) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
+// One wave per group of 64 tiles.  Per tile: the segments' pair counts -> their exclusive prefix (in place; all loads of
+// a tile in flight together) and the tile's total; per group: the tiles' exclusive prefix inside the group and the
+// group's total, from which one workgroup finishes the tile ranges (tile_order_kernel, mode 2).
+__global__ __launch_bounds__(64) void seg_prefix_kernel(uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ tile_tot,
+                                                        uint32_t* __restrict__ tile_loc, uint32_t* __restrict__ grp_sum,
+                                                        int ntiles, int nseg) {
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x * 64 + lane;
     uint32_t acc = 0;
-    for (int g = 0; g < nseg; g++) {
-        const uint32_t v = seg_cnt[(size_t)g * ntiles + t];
-        seg_cnt[(size_t)g * ntiles + t] = acc;
-        acc += v;
+    if (t < ntiles) {
+        for (int g0 = 0; g0 < nseg; g0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (g0 + k < nseg) ? seg_cnt[(size_t)(g0 + k) * ntiles + t] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (g0 + k < nseg) seg_cnt[(size_t)(g0 + k) * ntiles + t] = acc;
+                acc += v[k];
+            }
+        }
+        tile_tot[t] = acc;
     }
-    tile_tot[t] = acc;
+    uint32_t x = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (t < ntiles) tile_loc[t] = x - acc;
+    if (lane == 63) grp_sum[blockIdx.x] = x;
 }
 
 // Launch order of the per-tile render waves: tiles sorted by DESCENDING work estimate (a counting
@@ -289,7 +325,9 @@ template <bool HELD>
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ keys, int mode, int ntiles,
                                                           uint32_t* __restrict__ order, uint2* __restrict__ ranges_out,
-                                                          const PairCount pc, const FillJob fill) {
+                                                          const uint32_t* __restrict__ loc,
+                                                          const uint32_t* __restrict__ grp, const PairCount pc,
+                                                          const FillJob fill) {
     if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
@@ -318,23 +356,16 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
         for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
     }
     if (mode == 2) {
-        // tile ranges: exclusive scan of the counts in tile order, 1024 tiles per trip.  If the frame's pair count does
-        // not fit the state the lists were carved for, every range is left empty: the render that follows then draws an
-        // empty frame and touches nothing out of bounds (the host runs the phase again with a larger state).
+        // tile ranges (upstream identifyTileRanges): first pair of tile t = pairs of the 64-tile groups before its own
+        // (scanned here, 1024 groups per trip) + its prefix inside the group (seg_prefix_kernel).  If the frame's pair
+        // count does not fit the state the lists were carved for, every range is left empty: the render that follows
+        // then draws an empty frame and touches nothing out of bounds (the host runs the phase again, larger state).
         const bool fits = *pc.dev <= (unsigned long long)pc.cap;
+        const int ngrp = (ntiles + 63) / 64;
         __syncthreads();
-        for (int i0 = 0; i0 < ntiles; i0 += 1024) {
-            const int t = i0 + tid;
-            uint32_t v;
-            if (HELD) {
-                v = 0;
-#pragma unroll
-                for (int i = 0; i < PER; i++)
-                    if (i * 1024 == i0) v = held[i];
-            } else {
-                v = t < ntiles ? keys[t] : 0u;
-            }
-            if (!fits) v = 0u;
+        for (int g0 = 0; g0 < ngrp; g0 += 1024) {
+            const int g = g0 + tid;
+            const uint32_t v = g < ngrp ? grp[g] : 0u;
             uint32_t x = v;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -349,12 +380,17 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
                 woff += w < wid ? c : 0u;
                 tot += c;
             }
-            const uint32_t first = carry_s + woff + x - v;
-            if (t < ntiles) ranges_out[t] = make_uint2(first, first + v);
+            hist[tid] = carry_s + woff + x - v;  // first pair of group g (hist is free until the ordering below)
             __syncthreads();
+            const int t1 = min(ntiles, (g0 + 1024) * 64);
+            for (int t = g0 * 64 + tid; t < t1; t += 1024) {
+                const uint32_t first = hist[(t >> 6) - g0] + loc[t], n = keys[t];
+                ranges_out[t] = fits ? make_uint2(first, first + n) : make_uint2(0u, 0u);
+            }
             if (tid == 0) carry_s += tot;
             __syncthreads();
         }
+        hist[tid] = 0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
@@ -402,26 +438,27 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 }
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, uint32_t* ranges_out,
-                      PairCount pc, FillJob fill, int debug, hipStream_t s) {
+                      const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, int debug, hipStream_t s) {
     // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
     const size_t pieces = (fill.quads + 1023) / 1024;
     const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), pc, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill);
     else
         hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), pc, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }
 
 // The whole tile binning of one frame: counting pass, prefixes, ranges + launch order, writing pass.
-int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, uint32_t* seg_cnt, uint32_t* tile_tot, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
+int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts tc, uint32_t* ranges, uint32_t* order,
+                      uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
+    uint32_t* seg_cnt = tc.seg_cnt;
     const BinGrid G = bin_grid(gx, gy);
-    const int nseg = bin_segments(G, P);
-    const int seg_len = (((P + nseg - 1) / nseg) + TBK_THREADS - 1) / TBK_THREADS * TBK_THREADS;
+    const int seg_len = (((P + bin_segments(G, P) - 1) / bin_segments(G, P)) + TBK_CHUNK - 1) / TBK_CHUNK * TBK_CHUNK;
+    const int nseg = (P + seg_len - 1) / seg_len;  // (<= bin_segments: whole filter trips per segment)
     const int ntiles = gx * gy;
     const dim3 grid((unsigned)(G.nblocks * nseg));
     { StageScope sc_("tile_count", s);
@@ -429,10 +466,12 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, uint32_t* se
                        ntiles, seg_cnt, (const uint2*)nullptr, (uint32_t*)nullptr, pc);
     GS_LAUNCH_CHECK("tile_count", debug, s); }
     { StageScope sc_("seg_prefix", s);
-    hipLaunchKernelGGL(seg_prefix_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, seg_cnt, tile_tot, ntiles, nseg);
+    hipLaunchKernelGGL(seg_prefix_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, s, seg_cnt, tc.tile_tot, tc.tile_loc, tc.grp_sum,
+                       ntiles, nseg);
     GS_LAUNCH_CHECK("seg_prefix", debug, s); }
     { StageScope sc_("ranges_order", s);
-    const int rc = launch_tile_order(nullptr, tile_tot, 2, ntiles, order, ranges, pc, FillJob{nullptr, 0}, debug, s);
+    const int rc = launch_tile_order(nullptr, tc.tile_tot, 2, ntiles, order, ranges, tc.tile_loc, tc.grp_sum, pc,
+                                     FillJob{nullptr, 0}, debug, s);
     if (rc != GS_OK) return rc; }
     if (pc.cap > 0) {
         StageScope sc_("tile_write", s);

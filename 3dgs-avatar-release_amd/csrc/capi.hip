@@ -185,15 +185,18 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     int rc;
     if (a->P > 0) {
         point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
-        rc = launch_tile_lists((const uint4*)(g + L.ranklist), a->P, I.gx, I.gy, (uint32_t*)(im + I.seg_cnt),
-                               (uint32_t*)(im + I.tile_tot), ranges, (uint32_t*)(im + I.order),
+        rc = launch_tile_lists((const uint4*)(g + L.ranklist), a->P, I.gx, I.gy,
+                               TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), (uint32_t*)(im + I.tile_loc),
+                                          (uint32_t*)(im + I.grp_sum)},
+                               ranges, (uint32_t*)(im + I.order),
                                cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
         StageScope sc_("ranges_order", s);
-        rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), nullptr, pc, FillJob{nullptr, 0}, a->debug, s);
+        rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), nullptr, nullptr, nullptr, pc,
+                               FillJob{nullptr, 0}, a->debug, s);
         if (rc != GS_OK) return rc;
     }
     QuadLists ql;
@@ -356,7 +359,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr,
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr, nullptr, nullptr,
                                PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D}, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);

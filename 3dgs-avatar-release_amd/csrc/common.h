@@ -92,7 +92,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, total;
     int gx, gy;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -110,6 +110,8 @@ static inline ImgLayout img_layout(int W, int H) {
     L.order = take(nt * 4);
     L.seg_cnt = take(nt * 4 * (size_t)bin_grid(L.gx, L.gy).nseg_max);  // [segment][tile] pair counts, then their prefix
     L.tile_tot = take(nt * 4);                     // pairs per tile
+    L.tile_loc = take(nt * 4);                     // ... and their exclusive prefix inside the tile's group of 64 tiles
+    L.grp_sum = take((nt / 64 + 1) * 4);           // pairs per group of 64 tiles
     L.total = o;
     return L;
 }
@@ -205,8 +207,9 @@ int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* 
 // tile binning (binning.hip): rank list -> per-(segment, tile) counts -> ranges + launch order -> tile lists
 int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist, int P, int debug,
                      hipStream_t s);
-int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, uint32_t* seg_cnt, uint32_t* tile_tot, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
+struct TileCounts { uint32_t *seg_cnt, *tile_tot, *tile_loc, *grp_sum; };
+int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts tc, uint32_t* ranges, uint32_t* order,
+                      uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)
 int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
@@ -242,8 +245,11 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
 // `fill`: 16-byte words the kernel's other workgroups set to all-ones while the first one orders the tiles (the
 // backward's ROW_UNWRITTEN marks: a fill launch less, and it overlaps the single-workgroup ordering)
 struct FillJob { uint4* ptr; size_t quads; };
+// mode 0: work = ranges[t].y - ranges[t].x; mode 1: work = keys[4 t .. 4 t + 3] summed; mode 2: work = keys[t] = the
+// tile's pair count, and the tile ranges are written first from (loc, grp): see tile_order_kernel
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order,
-                      uint32_t* ranges_out, PairCount pc, FillJob fill, int debug, hipStream_t s);
+                      uint32_t* ranges_out, const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, int debug,
+                      hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
