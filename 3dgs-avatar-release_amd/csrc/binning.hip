@@ -109,42 +109,107 @@ __device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int b
     return hit;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
-                                                               int nbx, int nblocks, int seg_len, int ntiles,
-                                                               uint32_t* __restrict__ seg_cnt,
-                                                               const uint2* __restrict__ ranges,
-                                                               uint32_t* __restrict__ point_list, const PairCount pc) {
+// ---- counting pass.  How many Gaussians of rank segment g cover tile t?  A rectangle adds +1 / -1 at its four
+// corners of a (rows + 1) x (gx + 1) grid in LDS and a 2-D prefix sum turns the corners into coverage counts: four LDS
+// atomics per Gaussian instead of one per pair.  Workgroup (band of tile rows, segment); the band is the whole grid
+// unless the grid is too large for LDS.
+#define TC_CELLS 12288  // grid cells (4-byte) a workgroup holds
+__global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
+                                                                 int band_rows, int nbands, int seg_len, int ntiles,
+                                                                 uint32_t* __restrict__ seg_cnt) {
+    __shared__ int grid[TC_CELLS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int band = (int)blockIdx.x % nbands, sg = (int)blockIdx.x / nbands;
+    const int y0b = band * band_rows, y1b = min(gy, y0b + band_rows);
+    const int rows = y1b - y0b, ld = gx + 1;
+    const int cells = (rows + 1) * ld;
+    for (int k = tid; k < cells; k += TBK_THREADS) grid[k] = 0;
+    __syncthreads();
+    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
+    for (int rb = r0 + tid; rb < r1; rb += 4 * TBK_THREADS) {
+        uint4 e[4];  // four loads in flight per thread
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = rb + k * TBK_THREADS;
+            e[k] = r < r1 ? ranklist[r] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (e[k].w == 0u) continue;
+            const int x0 = (int)(e[k].y & 0xFFFFu), x1 = x0 + (int)(e[k].z & 0xFFFFu);
+            const int cy0 = max((int)(e[k].y >> 16), y0b) - y0b;
+            const int cy1 = min((int)(e[k].y >> 16) + (int)(e[k].z >> 16), y1b) - y0b;
+            if (cy1 <= cy0) continue;
+            atomicAdd(&grid[cy0 * ld + x0], 1);
+            atomicAdd(&grid[cy0 * ld + x1], -1);
+            atomicAdd(&grid[cy1 * ld + x0], -1);
+            atomicAdd(&grid[cy1 * ld + x1], 1);
+        }
+    }
+    __syncthreads();
+    // prefix down the columns (thread per column), then along the rows (a wave per row, 64 cells per trip)
+    for (int x = tid; x < ld; x += TBK_THREADS) {
+        int acc = 0;
+        for (int y = 0; y < rows; y++) {
+            acc += grid[y * ld + x];
+            grid[y * ld + x] = acc;
+        }
+    }
+    __syncthreads();
+    for (int y = wid; y < rows; y += TBK_WAVES) {
+        int carry = 0;
+        for (int x0 = 0; x0 < gx; x0 += 64) {
+            const int x = x0 + lane;
+            const int v = x < gx ? grid[y * ld + x] : 0;
+            int s = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(s, d, 64);
+                if (lane >= d) s += t;
+            }
+            if (x < gx) seg_cnt[(size_t)sg * ntiles + (size_t)(y0b + y) * gx + x] = (uint32_t)(carry + s);
+            carry += __shfl(s, 63, 64);
+        }
+    }
+}
+
+// ---- writing pass.  Workgroup (block of 64 x 4 tiles, segment).
+#define BM_LD 33  // words per tile in the bitmap (32 + 1: the tile-major rows fall into different banks)
+#define PRE_LD 34
+__global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
+                                                                 int nbx, int nblocks, int seg_len, int ntiles,
+                                                                 const uint32_t* __restrict__ seg_cnt,
+                                                                 const uint2* __restrict__ ranges,
+                                                                 uint32_t* __restrict__ point_list, const PairCount pc) {
     __shared__ uint32_t m_id[TBK_BUF], m_rc[TBK_BUF];
-    __shared__ uint32_t bitmap[WRITE ? 32 * TB_TILES : 1];         // [word][local tile]: a Gaussian's tiles hit consecutive banks
-    __shared__ unsigned short pre[WRITE ? 32 * TB_TILES : 1];     // pairs of the batch in the tile before word w
-    __shared__ unsigned short qtot[WRITE ? 4 * TB_TILES : 1];
-    __shared__ uint32_t run[TB_TILES], base[TB_TILES];
+    __shared__ uint32_t bitmap[TB_TILES * BM_LD];        // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
+    __shared__ unsigned short pre[TB_TILES * PRE_LD];    // pairs of the batch in the tile before word w
+    __shared__ unsigned short qtot[4 * TB_TILES];
+    __shared__ uint32_t dst[TB_TILES];                   // next free slot of every tile's list for this workgroup
     __shared__ uint32_t wcnt[TBK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
-    if (WRITE) {
-        if (*pc.dev > (unsigned long long)pc.cap) return;  // the list would not fit the state it was carved for: the host
-                                                           // sees the count and runs the phase again (workgroup-uniform)
-    }
+    if (*pc.dev > (unsigned long long)pc.cap) return;  // the lists would not fit the state they were carved for: the host
+                                                       // sees the count and runs the phase again (workgroup-uniform)
     if (tid < TB_TILES) {
-        run[tid] = 0u;
-        if (WRITE) {
-            const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
-            base[tid] = (tx < bx1 && ty < by1) ? ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx] : 0u;
-        }
+        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
+        dst[tid] = (tx < bx1 && ty < by1) ? ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx] : 0u;
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
     int count = 0;  // compacted Gaussians in the buffer (workgroup-uniform)
     __syncthreads();
-
-    // Every match is handled by a group of 16 lanes (four matches per wave and trip): lane j of the group takes the
-    // tiles j, j + 16, ... of the match's clipped rectangle (the average rectangle has ~12 tiles in a block).
     const int grp = lane >> 4, gl = lane & 15;
-    auto for_each_pair = [&](const int n, auto&& body) {
+
+    // one bitmap batch over the first n buffered Gaussians
+    auto process_batch = [&](const int n) {
+        const int nw = (n + 31) >> 5;
+        for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
+        __syncthreads();
+        // Gaussian-major: a group of 16 lanes per Gaussian (four per wave and trip), lane j takes the tiles j, j + 16, ...
+        // of its clipped rectangle (the average rectangle has ~12 tiles in a block)
         for (int m0 = wid * 4; m0 < n; m0 += TBK_WAVES * 4) {
             const int m = m0 + grp;
             if (m < n) {
@@ -153,27 +218,13 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
                 const uint32_t area = lw * lh, lx = rc & 63u, ly = (rc >> 6) & 3u;
                 for (uint32_t j = (uint32_t)gl; j < area; j += 16u) {
                     const uint32_t dy = (j >= lw ? 1u : 0u) + (j >= 2u * lw ? 1u : 0u) + (j >= 3u * lw ? 1u : 0u);
-                    body(m, (int)((ly + dy) * TB_W + lx + (j - dy * lw)));
+                    const uint32_t lt = (ly + dy) * TB_W + lx + (j - dy * lw);
+                    atomicOr(&bitmap[lt * BM_LD + (m >> 5)], 1u << (m & 31));
                 }
             }
         }
-    };
-
-    // one batch over the first n buffered Gaussians
-    auto process_batch = [&](const int n) {
-        if (!WRITE) {
-            // counting pass: only how many pairs each tile gets
-            for_each_pair(n, [&](int, int lt) { atomicAdd(&run[lt], 1u); });
-            __syncthreads();
-            return;
-        }
-        const int nw = (n + 31) >> 5;
-        for (int k = tid; k < nw * TB_TILES; k += TBK_THREADS) bitmap[k] = 0u;
         __syncthreads();
-        // bit m of tile lt's bitmap = "Gaussian m of the batch covers lt"
-        for_each_pair(n, [&](int m, int lt) { atomicOr(&bitmap[(m >> 5) * TB_TILES + lt], 1u << (m & 31)); });
-        __syncthreads();
-        // pre[w][lt] = pairs of tile lt in the words before w: thread (quarter q, tile lt) sums its 8 words, the quarters'
+        // pre[lt][w] = pairs of tile lt in the words before w: thread (quarter q, tile lt) sums its 8 words, the quarters'
         // totals are exchanged, then every thread writes the prefixes of its words
         {
             const int lt = tid & (TB_TILES - 1), q = tid >> 8;
@@ -181,7 +232,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int w = q * 8 + k;
-                c[k] = w < nw ? (uint32_t)__popc(bitmap[w * TB_TILES + lt]) : 0u;
+                c[k] = w < nw ? (uint32_t)__popc(bitmap[lt * BM_LD + w]) : 0u;
                 tot += c[k];
             }
             qtot[q * TB_TILES + lt] = (unsigned short)tot;
@@ -191,23 +242,32 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int w = q * 8 + k;
-                if (w < nw) pre[w * TB_TILES + lt] = (unsigned short)acc;
+                if (w < nw) pre[lt * PRE_LD + w] = (unsigned short)acc;
                 acc += c[k];
             }
         }
         __syncthreads();
-        // position of a pair in its tile's list: pairs of earlier segments and batches (base + run), then the
-        // Gaussians of this batch that come before it in the ranking and cover the tile too
-        for_each_pair(n, [&](int m, int lt) {
-            const int w = m >> 5;
-            const uint32_t rank = (uint32_t)pre[w * TB_TILES + lt] + __popc(bitmap[w * TB_TILES + lt] & ((1u << (m & 31)) - 1u));
-            point_list[base[lt] + run[lt] + rank] = m_id[m];
-        });
+        // Tile-major: a group of 16 lanes per tile expands the tile's bitmap words into its list -- the lanes of a group
+        // write into one contiguous run, so a store instruction touches a few lines (a Gaussian-major write-out scatters
+        // 64 lanes over 64 lists: measured 6x slower)
+        for (int lt0 = wid * 4; lt0 < TB_TILES; lt0 += TBK_WAVES * 4) {
+            const int lt = lt0 + grp;
+            const uint32_t d0 = dst[lt];
+            for (int w = gl; w < nw; w += 16) {
+                uint32_t bits = bitmap[lt * BM_LD + w];
+                uint32_t pos = d0 + pre[lt * PRE_LD + w];
+                while (bits) {
+                    const int bp = __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    point_list[pos++] = m_id[(w << 5) + bp];
+                }
+            }
+        }
         __syncthreads();
         if (tid < TB_TILES) {
             uint32_t c = 0;
             for (int q = 0; q < 4; q++) c += qtot[q * TB_TILES + tid];
-            run[tid] += c;
+            dst[tid] += c;
         }
         __syncthreads();
     };
@@ -266,10 +326,6 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_bin_kernel(const uint4* __re
             count = rem;
             __syncthreads();
         }
-    }
-    if (!WRITE && tid < TB_TILES) {
-        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
-        if (tx < bx1 && ty < by1) seg_cnt[(size_t)sg * ntiles + ty * gx + tx] = run[tid];
     }
 }
 
@@ -461,10 +517,17 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts t
     const int nseg = (P + seg_len - 1) / seg_len;  // (<= bin_segments: whole filter trips per segment)
     const int ntiles = gx * gy;
     const dim3 grid((unsigned)(G.nblocks * nseg));
-    { StageScope sc_("tile_count", s);
-    hipLaunchKernelGGL(tile_bin_kernel<false>, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
-                       ntiles, seg_cnt, (const uint2*)nullptr, (uint32_t*)nullptr, pc);
-    GS_LAUNCH_CHECK("tile_count", debug, s); }
+    {
+        // counting pass: bands of tile rows that fit the LDS grid (the whole tile grid up to ~110 x 110 tiles)
+        int band_rows = TC_CELLS / (gx + 1) - 1;
+        if (band_rows < 1) return GS_E_TOO_LARGE;  // (more than 12k tile columns)
+        if (band_rows > gy) band_rows = gy;
+        const int nbands = (gy + band_rows - 1) / band_rows;
+        StageScope sc_("tile_count", s);
+        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy,
+                           band_rows, nbands, seg_len, ntiles, seg_cnt);
+        GS_LAUNCH_CHECK("tile_count", debug, s);
+    }
     { StageScope sc_("seg_prefix", s);
     hipLaunchKernelGGL(seg_prefix_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, s, seg_cnt, tc.tile_tot, tc.tile_loc, tc.grp_sum,
                        ntiles, nseg);
@@ -475,7 +538,7 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts t
     if (rc != GS_OK) return rc; }
     if (pc.cap > 0) {
         StageScope sc_("tile_write", s);
-        hipLaunchKernelGGL(tile_bin_kernel<true>, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
+        hipLaunchKernelGGL(tile_write_kernel, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
                            ntiles, seg_cnt, reinterpret_cast<const uint2*>(ranges), point_list, pc);
         GS_LAUNCH_CHECK("tile_write", debug, s);
     }

@@ -559,6 +559,16 @@ int gs_profile_enable(int on) {
     g_prof.on = on != 0;
     return GS_OK;
 }
+int gs_profile_reserve(int n_events) {
+    // hipEventCreate costs ~0.1-0.2 ms: creating events inside a timed loop shows up as slow first steps
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    while ((int)g_prof.pool.size() < n_events) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return GS_E_HIP;
+        g_prof.pool.push_back(e);
+    }
+    return GS_OK;
+}
 int gs_profile_filter(const char* stage) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     memset(g_prof.filter, 0, sizeof(g_prof.filter));

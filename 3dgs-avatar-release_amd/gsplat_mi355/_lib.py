@@ -31,7 +31,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
-           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning"]
+           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_ADAM_MAX_TENSORS = 16
@@ -102,6 +102,7 @@ def load():
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_tuning.argtypes = [c_char_p, c_int]
+        L.gs_profile_reserve.argtypes = [c_int]
         L.gs_profile_enable.argtypes = [c_int]
         L.gs_profile_filter.argtypes = [c_char_p]
         L.gs_profile_collect.argtypes = [c_int, POINTER(c_char_p), POINTER(c_float), POINTER(c_int32), POINTER(c_int32)]
@@ -133,6 +134,11 @@ def profile_enable(on, stage=None):
     """Per-stage hipEvent timing on/off; `stage` restricts it to one stage (two events per call)."""
     check(load().gs_profile_filter(stage.encode() if stage else None))
     check(load().gs_profile_enable(1 if on else 0))
+
+
+def profile_reserve(n_events):
+    """Pre-creates HIP events for the stage timers (event creation is slow: keep it out of timed regions)."""
+    check(load().gs_profile_reserve(int(n_events)))
 
 
 def profile_collect(max_stages=32):

@@ -345,6 +345,7 @@ def main(argv=None):
         # untimed: ~0.7 s of back-to-back steps right before the warm-up, so that the chip's clocks have settled under
         # THIS load (the statistics above leave the GPU idle for a while; a timed region that starts on an idle chip
         # reads 10-25 % slow for its first hundreds of steps), then the W warm-up steps and the K timed ones
+        _lib.profile_reserve(2 * K + 64)  # the timed loop records two events per step: none may be CREATED inside it
         t_end = time.perf_counter() + 0.7
         while time.perf_counter() < t_end:
             for i in range(8):
@@ -358,8 +359,15 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        trace = os.environ.get("GSPLAT_BENCH_TRACE") == "1"  # diagnostics only: a synchronise + a line every 25 steps
         for i in range(K):
             step(8 + Wm + i)
+            if trace and i % 25 == 24:
+                torch.cuda.synchronize()
+                st = torch.cuda.memory_stats(dev)
+                print("[trace] leg tile_rect=%d step %d: %.4f ms/step so far, reserved %.0f MB, allocs %d, num_ooms %d, last count %s" % (
+                    tile_rect, i + 1, (time.perf_counter() - t0) / (i + 1) * 1e3, st["reserved_bytes.all.current"] / 1e6,
+                    st["allocation.all.allocated"], st["num_ooms"], dgr._last_count.get((dev.index, N, W, H))), file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

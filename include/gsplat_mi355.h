@@ -262,6 +262,7 @@ int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
  * bracketed by a pair of hipEvents recorded ON THE STAGE'S OWN STREAM.  gs_profile_collect waits for
  * the recorded events, sums the elapsed milliseconds and launch counts per stage name (first `max`
  * distinct stages, names are static strings) and clears the record. ---- */
+int gs_profile_reserve(int n_events); /* pre-create events so that none is created inside a timed region */
 int gs_profile_enable(int on);
 int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
 int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
