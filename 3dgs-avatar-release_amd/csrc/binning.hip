@@ -91,8 +91,8 @@ int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_
 #define TBK_THREADS 1024
 #define TBK_WAVES (TBK_THREADS / 64)
 #define TBK_BATCH 1024   // Gaussians per bitmap batch (32 words per tile)
-#define TBK_CHUNK 2048   // ranks filtered per trip (128 per wave)
-#define TBK_BUF (TBK_BATCH + TBK_CHUNK)  // compacted Gaussians waiting for a batch: < 1024 carried + <= 2048 new
+#define TBK_CHUNK 4096   // ranks filtered per trip (256 per wave, 4 per lane)
+#define TBK_BUF (TBK_BATCH + TBK_CHUNK)  // compacted Gaussians waiting for a batch: < 1024 carried + <= 4096 new
 
 // a match's rectangle clipped to the block, in block-local tile coordinates: lx (6 bits) | ly (2) | w - 1 (6) | h - 1 (2)
 __device__ __forceinline__ uint32_t pack_local_rect(int lx, int ly, int lw, int lh) {
@@ -173,41 +173,52 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __
     }
 }
 
-// ---- writing pass.  Workgroup (block of 64 x 4 tiles, segment).
-#define BM_LD 33  // words per tile in the bitmap (32 + 1: the tile-major rows fall into different banks)
-#define PRE_LD 34
+// ---- writing pass.  Workgroup (block of 64 x 4 tiles, segment).  The kernel's arithmetic is trivial; what it is built
+// around is the number of DEPENDENT steps (global-load latencies and workgroup barriers) a workgroup goes through: all
+// first loads are issued together, the filter takes two trips of 4096 ranks with one barrier pair each, and a bitmap
+// batch needs two barriers.
+#define BM_LD 33          // words per tile in the bitmap (32 + 1: tile-major rows fall into different banks)
 __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
                                                                  int nbx, int nblocks, int seg_len, int ntiles,
                                                                  const uint32_t* __restrict__ seg_cnt,
                                                                  const uint2* __restrict__ ranges,
                                                                  uint32_t* __restrict__ point_list, const PairCount pc) {
     __shared__ uint32_t m_id[TBK_BUF], m_rc[TBK_BUF];
-    __shared__ uint32_t bitmap[TB_TILES * BM_LD];        // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
-    __shared__ unsigned short pre[TB_TILES * PRE_LD];    // pairs of the batch in the tile before word w
-    __shared__ unsigned short qtot[4 * TB_TILES];
-    __shared__ uint32_t dst[TB_TILES];                   // next free slot of every tile's list for this workgroup
+    __shared__ uint32_t bitmap[TB_TILES * BM_LD];  // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
+    __shared__ uint32_t dst[TB_TILES];             // next free slot of every tile's list for this workgroup
     __shared__ uint32_t wcnt[TBK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
-    if (*pc.dev > (unsigned long long)pc.cap) return;  // the lists would not fit the state they were carved for: the host
-                                                       // sees the count and runs the phase again (workgroup-uniform)
+    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
+    // everything the workgroup needs first, in flight together: the first trip's ranks, the list bases, the pair count
+    uint4 e[4];
+    auto load_trip = [&](const int rb) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = rb + wid * 256 + k * 64 + lane;  // a wave owns 256 consecutive ranks of the trip
+            e[k] = r < r1 ? ranklist[r] : make_uint4(0, 0, 0, 0);  // (tiles touched = 0: never a match)
+        }
+    };
+    load_trip(r0);
+    uint32_t my_dst = 0;
     if (tid < TB_TILES) {
         const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
-        dst[tid] = (tx < bx1 && ty < by1) ? ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx] : 0u;
+        if (tx < bx1 && ty < by1) my_dst = ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx];
     }
+    const unsigned long long frame_pairs = *pc.dev;
+    for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
+    if (frame_pairs > (unsigned long long)pc.cap) return;  // the lists would not fit the state they were carved for: the host
+                                                           // sees the count and runs the phase again (workgroup-uniform)
+    if (tid < TB_TILES) dst[tid] = my_dst;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
     int count = 0;  // compacted Gaussians in the buffer (workgroup-uniform)
-    __syncthreads();
     const int grp = lane >> 4, gl = lane & 15;
 
-    // one bitmap batch over the first n buffered Gaussians
+    // One bitmap batch over the first n buffered Gaussians (the bitmap is all zero on entry and on exit).
     auto process_batch = [&](const int n) {
         const int nw = (n + 31) >> 5;
-        for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
-        __syncthreads();
         // Gaussian-major: a group of 16 lanes per Gaussian (four per wave and trip), lane j takes the tiles j, j + 16, ...
         // of its clipped rectangle (the average rectangle has ~12 tiles in a block)
         for (int m0 = wid * 4; m0 < n; m0 += TBK_WAVES * 4) {
@@ -224,89 +235,75 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             }
         }
         __syncthreads();
-        // pre[lt][w] = pairs of tile lt in the words before w: thread (quarter q, tile lt) sums its 8 words, the quarters'
-        // totals are exchanged, then every thread writes the prefixes of its words
-        {
-            const int lt = tid & (TB_TILES - 1), q = tid >> 8;
-            uint32_t c[8], tot = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int w = q * 8 + k;
-                c[k] = w < nw ? (uint32_t)__popc(bitmap[lt * BM_LD + w]) : 0u;
-                tot += c[k];
-            }
-            qtot[q * TB_TILES + lt] = (unsigned short)tot;
-            __syncthreads();
-            uint32_t acc = 0;
-            for (int qq = 0; qq < q; qq++) acc += qtot[qq * TB_TILES + lt];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int w = q * 8 + k;
-                if (w < nw) pre[lt * PRE_LD + w] = (unsigned short)acc;
-                acc += c[k];
-            }
-        }
-        __syncthreads();
-        // Tile-major: a group of 16 lanes per tile expands the tile's bitmap words into its list -- the lanes of a group
-        // write into one contiguous run, so a store instruction touches a few lines (a Gaussian-major write-out scatters
-        // 64 lanes over 64 lists: measured 6x slower)
+        // Tile-major: a group of 16 lanes per tile expands the tile's bitmap words into its list (lane j: words j and
+        // j + 16; the words' offsets inside the tile's run are a 16-lane prefix sum of their popcounts).  The lanes of a
+        // group write into one contiguous run, so a store instruction touches a few lines -- a Gaussian-major write-out
+        // scatters 64 lanes over 64 lists (measured 6x slower on the whole kernel).
         for (int lt0 = wid * 4; lt0 < TB_TILES; lt0 += TBK_WAVES * 4) {
             const int lt = lt0 + grp;
-            const uint32_t d0 = dst[lt];
-            for (int w = gl; w < nw; w += 16) {
-                uint32_t bits = bitmap[lt * BM_LD + w];
-                uint32_t pos = d0 + pre[lt * PRE_LD + w];
-                while (bits) {
-                    const int bp = __ffs((int)bits) - 1;
-                    bits &= bits - 1u;
-                    point_list[pos++] = m_id[(w << 5) + bp];
-                }
+            uint32_t bits0 = 0, bits1 = 0;
+            if (gl < nw) { bits0 = bitmap[lt * BM_LD + gl]; bitmap[lt * BM_LD + gl] = 0u; }
+            if (gl + 16 < nw) { bits1 = bitmap[lt * BM_LD + gl + 16]; bitmap[lt * BM_LD + gl + 16] = 0u; }
+            const uint32_t c0 = (uint32_t)__popc(bits0), c1 = (uint32_t)__popc(bits1);
+            uint32_t x0 = c0, x1 = c1;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t y0 = __shfl_up(x0, d, 16), y1 = __shfl_up(x1, d, 16);
+                if (gl >= d) { x0 += y0; x1 += y1; }
             }
-        }
-        __syncthreads();
-        if (tid < TB_TILES) {
-            uint32_t c = 0;
-            for (int q = 0; q < 4; q++) c += qtot[q * TB_TILES + tid];
-            dst[tid] += c;
+            const uint32_t tot0 = __shfl(x0, 15, 16), tot1 = __shfl(x1, 15, 16);
+            const uint32_t d0 = dst[lt];
+            uint32_t pos = d0 + x0 - c0;
+            while (bits0) {
+                const int bp = __ffs((int)bits0) - 1;
+                bits0 &= bits0 - 1u;
+                point_list[pos++] = m_id[(gl << 5) + bp];
+            }
+            pos = d0 + tot0 + x1 - c1;
+            while (bits1) {
+                const int bp = __ffs((int)bits1) - 1;
+                bits1 &= bits1 - 1u;
+                point_list[pos++] = m_id[((gl + 16) << 5) + bp];
+            }
+            if (gl == 0) dst[lt] = d0 + tot0 + tot1;  // (only this group touches tile lt)
         }
         __syncthreads();
     };
 
-    // Filter: wave w owns ranks [rb + 128 w, rb + 128 w + 128) of the trip, two per lane, so the compaction needs no
-    // workgroup barrier per 64 ranks: one barrier for the waves' counts, then every wave writes its matches (rank order)
-    // at its offset.  The next trip's entries are loaded before this trip's are processed.
-    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
-    auto load_trip = [&](const int rb) {
-        const int ra = rb + wid * 128 + lane, rbb = ra + 64;
-        e0 = ra < r1 ? ranklist[ra] : make_uint4(0, 0, 0, 0);   // (tiles touched = 0: never a match)
-        e1 = rbb < r1 ? ranklist[rbb] : make_uint4(0, 0, 0, 0);
-    };
-    if (r0 < r1) load_trip(r0);
+    // Filter: the wave's 256 ranks are compacted with four ballots; one barrier for the waves' counts, then every wave
+    // writes its matches (rank order) at its offset.  The next trip's entries are loaded before this trip's are used.
+    __syncthreads();
     for (int rb = r0; rb < r1 || count > 0;) {
         if (rb < r1) {
-            uint32_t rc0, rc1;
-            const bool h0 = block_hit(e0, bx0, by0, bx1, by1, &rc0), h1 = block_hit(e1, bx0, by0, bx1, by1, &rc1);
-            const uint32_t id0 = e0.x, id1 = e1.x;
-            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
-            const int c0 = __popcll(b0), c1 = __popcll(b1);
-            if (lane == 0) wcnt[wid] = (uint32_t)(c0 + c1);
+            uint32_t rc[4], id[4];
+            unsigned long long bal[4];
+            int c[4], csum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool h = block_hit(e[k], bx0, by0, bx1, by1, &rc[k]);
+                id[k] = e[k].x;
+                bal[k] = __ballot(h);
+                c[k] = __popcll(bal[k]);
+                csum += c[k];
+            }
+            if (lane == 0) wcnt[wid] = (uint32_t)csum;
             if (rb + TBK_CHUNK < r1) load_trip(rb + TBK_CHUNK);
             __syncthreads();
             uint32_t woff = 0, tot = 0;
             for (int w = 0; w < TBK_WAVES; w++) {
-                const uint32_t c = wcnt[w];
-                woff += w < wid ? c : 0u;
-                tot += c;
+                const uint32_t cw = wcnt[w];
+                woff += w < wid ? cw : 0u;
+                tot += cw;
             }
-            if (h0) {
-                const int slot = count + (int)woff + __popcll(b0 & lt_mask);
-                m_id[slot] = id0;
-                m_rc[slot] = rc0;
-            }
-            if (h1) {
-                const int slot = count + (int)woff + c0 + __popcll(b1 & lt_mask);
-                m_id[slot] = id1;
-                m_rc[slot] = rc1;
+            int slot0 = count + (int)woff;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((bal[k] >> lane) & 1ull) {
+                    const int slot = slot0 + __popcll(bal[k] & lt_mask);
+                    m_id[slot] = id[k];
+                    m_rc[slot] = rc[k];
+                }
+                slot0 += c[k];
             }
             count += (int)tot;
             rb += TBK_CHUNK;
@@ -316,13 +313,20 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         while (count >= TBK_BATCH || (last && count > 0)) {
             const int n = min(count, TBK_BATCH);
             process_batch(n);
-            const int rem = count - n;  // < 2048: at most two elements per thread move to the front
-            uint32_t cid0 = 0, crc0 = 0, cid1 = 0, crc1 = 0;
-            if (tid < rem) { cid0 = m_id[n + tid]; crc0 = m_rc[n + tid]; }
-            if (tid + TBK_THREADS < rem) { cid1 = m_id[n + tid + TBK_THREADS]; crc1 = m_rc[n + tid + TBK_THREADS]; }
+            const int rem = count - n;  // < 4096: at most four elements per thread move to the front
+            uint32_t cid[4], crc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = tid + k * TBK_THREADS;
+                cid[k] = i < rem ? m_id[n + i] : 0u;
+                crc[k] = i < rem ? m_rc[n + i] : 0u;
+            }
             __syncthreads();
-            if (tid < rem) { m_id[tid] = cid0; m_rc[tid] = crc0; }
-            if (tid + TBK_THREADS < rem) { m_id[tid + TBK_THREADS] = cid1; m_rc[tid + TBK_THREADS] = crc1; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = tid + k * TBK_THREADS;
+                if (i < rem) { m_id[i] = cid[k]; m_rc[i] = crc[k]; }
+            }
             count = rem;
             __syncthreads();
         }
@@ -513,7 +517,7 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts t
                       uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
     uint32_t* seg_cnt = tc.seg_cnt;
     const BinGrid G = bin_grid(gx, gy);
-    const int seg_len = (((P + bin_segments(G, P) - 1) / bin_segments(G, P)) + TBK_CHUNK - 1) / TBK_CHUNK * TBK_CHUNK;
+    const int seg_len = (((P + bin_segments(G, P) - 1) / bin_segments(G, P)) + TBK_CHUNK - 1) / TBK_CHUNK * TBK_CHUNK;  // whole filter trips
     const int nseg = (P + seg_len - 1) / seg_len;  // (<= bin_segments: whole filter trips per segment)
     const int ntiles = gx * gy;
     const dim3 grid((unsigned)(G.nblocks * nseg));

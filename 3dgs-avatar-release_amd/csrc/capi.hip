@@ -560,13 +560,18 @@ int gs_profile_enable(int on) {
     return GS_OK;
 }
 int gs_profile_reserve(int n_events) {
-    // hipEventCreate costs ~0.1-0.2 ms: creating events inside a timed loop shows up as slow first steps
+    // creating an event and RECORDING it for the first time each cost ~0.1 ms: done here, a timed loop would otherwise
+    // show them as slow first steps
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t last = nullptr;
     while ((int)g_prof.pool.size() < n_events) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return GS_E_HIP;
+        (void)hipEventRecord(e, nullptr);
+        last = e;
         g_prof.pool.push_back(e);
     }
+    if (last) (void)hipEventSynchronize(last);
     return GS_OK;
 }
 int gs_profile_filter(const char* stage) {
