@@ -69,18 +69,29 @@ int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* 
 // tiles touched) -- 16 bytes streamed by the binning workgroups instead of a 48-byte record gathered per rank.
 __global__ __launch_bounds__(256) void rank_list_kernel(const uint32_t* __restrict__ sorted_idx,
                                                         const float4* __restrict__ rec, const uint32_t* __restrict__ tiles,
-                                                        uint4* __restrict__ ranklist, int P) {
+                                                        uint4* __restrict__ ranklist, uint32_t* __restrict__ chunk_pairs,
+                                                        int P) {
+    __shared__ uint32_t ws[4];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t id = sorted_idx[r];
-    const float4 c = rec[(size_t)id * 3 + 2];
-    ranklist[r] = make_uint4(id, __float_as_uint(c.z), __float_as_uint(c.w), tiles[id]);
+    uint32_t tt = 0;
+    if (r < P) {
+        const uint32_t id = sorted_idx[r];
+        const float4 c = rec[(size_t)id * 3 + 2];
+        tt = tiles[id];
+        ranklist[r] = make_uint4(id, __float_as_uint(c.z), __float_as_uint(c.w), tt);
+    }
+    // pairs of this chunk of 256 ranks: the binning workgroups cut the ranking into segments of equal WORK with it
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tt += __shfl_xor(tt, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_pairs[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist, int P, int debug,
-                     hipStream_t s) {
+int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist,
+                     uint32_t* chunk_pairs, int P, int debug, hipStream_t s) {
     hipLaunchKernelGGL(rank_list_kernel, dim3((P + 255) / 256), dim3(256), 0, s, sorted_idx,
-                       reinterpret_cast<const float4*>(rec), tiles, ranklist, P);
+                       reinterpret_cast<const float4*>(rec), tiles, ranklist, chunk_pairs, P);
     GS_LAUNCH_CHECK("rank_list", debug, s);
     return GS_OK;
 }
@@ -109,23 +120,80 @@ __device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int b
     return hit;
 }
 
+// The ranking is cut into `nseg` SEGMENTS of about equal work, not of equal length: the nearest Gaussians come first
+// and cover hundreds of tiles each, so equal-length segments leave the workgroups of the first segments with ten times
+// the pairs of the others (they then ARE the kernel's run time).  Work of a chunk of 256 ranks = its pairs + SEG_RANK_W
+// (the cost of filtering 256 ranks, in pairs); chunk c belongs to segment floor(nseg * work before c / total work), so the
+// segments are contiguous runs of chunks (possibly empty).  Every workgroup derives the run of its segment itself: one
+// load of the chunk sums and a 1024-wide scan.  Returns the rank range [*r0, *r1) of segment sg.
+#define SEG_RANK_W 4096u
+__device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
+                                               unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nchunks = (P + 255) / 256;
+    const int per = (nchunks + TBK_THREADS - 1) / TBK_THREADS;  // consecutive chunks per thread
+    const int c0 = tid * per;
+    unsigned long long mine = 0;
+    for (int k = 0; k < per; k++)
+        if (c0 + k < nchunks) mine += (unsigned long long)chunk_pairs[c0 + k] + SEG_RANK_W;
+    unsigned long long x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    int* bounds = reinterpret_cast<int*>(scratch + TBK_WAVES);
+    if (lane == 63) scratch[wid] = x;
+    if (tid == 0) { bounds[0] = nchunks; bounds[1] = nchunks; }
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+    for (int w = 0; w < TBK_WAVES; w++) {
+        const unsigned long long c = scratch[w];
+        woff += w < wid ? c : 0ull;
+        total += c;
+    }
+    unsigned long long before = woff + x - mine;  // work before this thread's first chunk
+    int prev_seg = -1;  // segment of the chunk before this thread's first one
+    if (c0 > 0 && c0 <= nchunks) {
+        // (the previous chunk's "work before" is not known here, but its segment is < the first one of ours unless equal:
+        // recompute it from its own work)
+        const unsigned long long pw = (unsigned long long)chunk_pairs[c0 - 1] + SEG_RANK_W;
+        prev_seg = (int)min((unsigned long long)(nseg - 1), (before - pw) * (unsigned long long)nseg / total);
+    }
+    for (int k = 0; k < per; k++) {
+        const int c = c0 + k;
+        if (c >= nchunks) break;
+        const int sgc = (int)min((unsigned long long)(nseg - 1), before * (unsigned long long)nseg / total);
+        if (sgc >= sg && prev_seg < sg) bounds[0] = c;           // first chunk of segment sg or later
+        if (sgc >= sg + 1 && prev_seg < sg + 1) bounds[1] = c;   // first chunk past segment sg
+        prev_seg = sgc;
+        before += (unsigned long long)chunk_pairs[c] + SEG_RANK_W;
+    }
+    __syncthreads();
+    *r0 = min(P, bounds[0] * 256);
+    *r1 = min(P, bounds[1] * 256);
+    __syncthreads();
+}
+
 // ---- counting pass.  How many Gaussians of rank segment g cover tile t?  A rectangle adds +1 / -1 at its four
 // corners of a (rows + 1) x (gx + 1) grid in LDS and a 2-D prefix sum turns the corners into coverage counts: four LDS
 // atomics per Gaussian instead of one per pair.  Workgroup (band of tile rows, segment); the band is the whole grid
 // unless the grid is too large for LDS.
 #define TC_CELLS 12288  // grid cells (4-byte) a workgroup holds
-__global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
-                                                                 int band_rows, int nbands, int seg_len, int ntiles,
+__global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist,
+                                                                 const uint32_t* __restrict__ chunk_pairs, int P, int gx,
+                                                                 int gy, int band_rows, int nbands, int nseg, int ntiles,
                                                                  uint32_t* __restrict__ seg_cnt) {
     __shared__ int grid[TC_CELLS];
+    __shared__ unsigned long long sb_scratch[20];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int band = (int)blockIdx.x % nbands, sg = (int)blockIdx.x / nbands;
     const int y0b = band * band_rows, y1b = min(gy, y0b + band_rows);
     const int rows = y1b - y0b, ld = gx + 1;
     const int cells = (rows + 1) * ld;
     for (int k = tid; k < cells; k += TBK_THREADS) grid[k] = 0;
-    __syncthreads();
-    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
+    int r0, r1;
+    segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);  // (its barriers also cover the zeroing above)
     for (int rb = r0 + tid; rb < r1; rb += 4 * TBK_THREADS) {
         uint4 e[4];  // four loads in flight per thread
 #pragma unroll
@@ -178,8 +246,9 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __
 // first loads are issued together, the filter takes two trips of 4096 ranks with one barrier pair each, and a bitmap
 // batch needs two barriers.
 #define BM_LD 33          // words per tile in the bitmap (32 + 1: tile-major rows fall into different banks)
-__global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist, int P, int gx, int gy,
-                                                                 int nbx, int nblocks, int seg_len, int ntiles,
+__global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist,
+                                                                 const uint32_t* __restrict__ chunk_pairs, int P, int gx,
+                                                                 int gy, int nbx, int nblocks, int nseg, int ntiles,
                                                                  const uint32_t* __restrict__ seg_cnt,
                                                                  const uint2* __restrict__ ranges,
                                                                  uint32_t* __restrict__ point_list, const PairCount pc) {
@@ -187,12 +256,21 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     __shared__ uint32_t bitmap[TB_TILES * BM_LD];  // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
     __shared__ uint32_t dst[TB_TILES];             // next free slot of every tile's list for this workgroup
     __shared__ uint32_t wcnt[TBK_WAVES];
+    __shared__ unsigned long long sb_scratch[20];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
-    const int r0 = sg * seg_len, r1 = min(P, r0 + seg_len);
-    // everything the workgroup needs first, in flight together: the first trip's ranks, the list bases, the pair count
+    // the list bases and the pair count are requested before the segment's rank range is worked out
+    uint32_t my_dst = 0;
+    if (tid < TB_TILES) {
+        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
+        if (tx < bx1 && ty < by1) my_dst = ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx];
+    }
+    const unsigned long long frame_pairs = *pc.dev;
+    for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
+    int r0, r1;
+    segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
     uint4 e[4];
     auto load_trip = [&](const int rb) {
 #pragma unroll
@@ -202,13 +280,6 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         }
     };
     load_trip(r0);
-    uint32_t my_dst = 0;
-    if (tid < TB_TILES) {
-        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
-        if (tx < bx1 && ty < by1) my_dst = ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx];
-    }
-    const unsigned long long frame_pairs = *pc.dev;
-    for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
     if (frame_pairs > (unsigned long long)pc.cap) return;  // the lists would not fit the state they were carved for: the host
                                                            // sees the count and runs the phase again (workgroup-uniform)
     if (tid < TB_TILES) dst[tid] = my_dst;
@@ -513,12 +584,11 @@ int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, in
 }
 
 // The whole tile binning of one frame: counting pass, prefixes, ranges + launch order, writing pass.
-int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts tc, uint32_t* ranges, uint32_t* order,
-                      uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
+int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
+                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
     uint32_t* seg_cnt = tc.seg_cnt;
     const BinGrid G = bin_grid(gx, gy);
-    const int seg_len = (((P + bin_segments(G, P) - 1) / bin_segments(G, P)) + TBK_CHUNK - 1) / TBK_CHUNK * TBK_CHUNK;  // whole filter trips
-    const int nseg = (P + seg_len - 1) / seg_len;  // (<= bin_segments: whole filter trips per segment)
+    const int nseg = bin_segments(G, P);  // segments of about equal work (segment_bounds)
     const int ntiles = gx * gy;
     const dim3 grid((unsigned)(G.nblocks * nseg));
     {
@@ -528,8 +598,8 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts t
         if (band_rows > gy) band_rows = gy;
         const int nbands = (gy + band_rows - 1) / band_rows;
         StageScope sc_("tile_count", s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy,
-                           band_rows, nbands, seg_len, ntiles, seg_cnt);
+        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TBK_THREADS), 0, s, ranklist, chunk_pairs, P,
+                           gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt);
         GS_LAUNCH_CHECK("tile_count", debug, s);
     }
     { StageScope sc_("seg_prefix", s);
@@ -542,8 +612,8 @@ int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts t
     if (rc != GS_OK) return rc; }
     if (pc.cap > 0) {
         StageScope sc_("tile_write", s);
-        hipLaunchKernelGGL(tile_write_kernel, grid, dim3(TBK_THREADS), 0, s, ranklist, P, gx, gy, G.nbx, G.nblocks, seg_len,
-                           ntiles, seg_cnt, reinterpret_cast<const uint2*>(ranges), point_list, pc);
+        hipLaunchKernelGGL(tile_write_kernel, grid, dim3(TBK_THREADS), 0, s, ranklist, chunk_pairs, P, gx, gy, G.nbx, G.nblocks,
+                           nseg, ntiles, seg_cnt, reinterpret_cast<const uint2*>(ranges), point_list, pc);
         GS_LAUNCH_CHECK("tile_write", debug, s);
     }
     return GS_OK;

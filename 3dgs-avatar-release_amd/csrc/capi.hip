@@ -145,8 +145,8 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         if (rc != GS_OK) return rc;
         // 4 passes -> the sorted index ends in (k0, v0)
         { StageScope sc_("rank_list", s);
-        rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist), a->P,
-                              a->debug, s); }
+        rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist),
+                              (uint32_t*)(g + L.chunk_pairs), a->P, a->debug, s); }
         if (rc != GS_OK) return rc;
     }
     if (count_host_pinned && (!poll || a->P == 0)) {
@@ -185,7 +185,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     int rc;
     if (a->P > 0) {
         point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
-        rc = launch_tile_lists((const uint4*)(g + L.ranklist), a->P, I.gx, I.gy,
+        rc = launch_tile_lists((const uint4*)(g + L.ranklist), (const uint32_t*)(g + L.chunk_pairs), a->P, I.gx, I.gy,
                                TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), (uint32_t*)(im + I.tile_loc),
                                           (uint32_t*)(im + I.grp_sum)},
                                ranges, (uint32_t*)(im + I.order),

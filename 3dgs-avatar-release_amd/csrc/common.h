@@ -27,7 +27,7 @@ static inline size_t sort_table_words(size_t n) {
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
 struct GeomLayout {
-    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, wsum, hist, count, total;
+    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, hist, count, total;
     int nblk_sort, nwaves;
 };
 static inline GeomLayout geom_layout(int P) {
@@ -46,6 +46,7 @@ static inline GeomLayout geom_layout(int P) {
     L.val0 = take(n * 4);
     L.val1 = take(n * 4);
     L.ranklist = take(n * 16);               // (index, rect min, rect size, tiles touched) in depth-rank order
+    L.chunk_pairs = take(((n + 255) / 256) * 4);  // tiles touched per chunk of 256 consecutive ranks
     L.wsum = take((size_t)L.nwaves * 4);     // tiles touched per preprocess wave
     L.hist = take(sort_table_words(n) * 4);
     L.count = take(64);
@@ -205,11 +206,11 @@ static inline void sort_totals_region(uint32_t* hist, int64_t n, int bits, uint3
 int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* rec, unsigned long long* count,
                       unsigned long long* host_count, int P, int debug, hipStream_t s);
 // tile binning (binning.hip): rank list -> per-(segment, tile) counts -> ranges + launch order -> tile lists
-int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist, int P, int debug,
-                     hipStream_t s);
+int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist,
+                     uint32_t* chunk_pairs, int P, int debug, hipStream_t s);
 struct TileCounts { uint32_t *seg_cnt, *tile_tot, *tile_loc, *grp_sum; };
-int launch_tile_lists(const uint4* ranklist, int P, int gx, int gy, TileCounts tc, uint32_t* ranges, uint32_t* order,
-                      uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
+int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
+                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)
 int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
