@@ -23,6 +23,7 @@ run as child processes of this command before it touches the GPU itself (--no-pm
 """
 import argparse
 import csv
+import gc
 import glob
 import json
 import math
@@ -345,7 +346,12 @@ def main(argv=None):
         # untimed: ~0.7 s of back-to-back steps right before the warm-up, so that the chip's clocks have settled under
         # THIS load (the statistics above leave the GPU idle for a while; a timed region that starts on an idle chip
         # reads 10-25 % slow for its first hundreds of steps), then the W warm-up steps and the K timed ones
-        _lib.profile_reserve(2 * K + 64)  # the timed loop records two events per step: none may be CREATED inside it
+        # The timed loop brackets the dominant kernel with two HIP events per step.  Creating an event and recording it
+        # for the first time cost ~0.1-0.2 ms each (seen as a timed loop whose first steps take 3-4 ms): the stage timer
+        # therefore already runs during the settle and warm-up steps below, so that every event the timed loop takes from
+        # the pool has been created AND recorded on this stream before.
+        _lib.profile_reserve(2 * K + 64)
+        _lib.profile_enable(True, stage=dominant)
         t_end = time.perf_counter() + 0.7
         while time.perf_counter() < t_end:
             for i in range(8):
@@ -353,16 +359,28 @@ def main(argv=None):
             torch.cuda.synchronize()
         for i in range(Wm):
             step(8 + i)
-        _lib.profile_enable(True, stage=dominant)  # two HIP events per step around the dominant kernel only
         torch.cuda.synchronize()
+        _lib.profile_collect()  # returns every event used so far to the pool: the timed loop takes them from there
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # A full collection of the interpreter's cyclic garbage collector walks every object torch has created at import
+        # (60-100 ms, observed as ONE step of the timed loop taking that long): collect now, keep it off while timing.
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         trace = os.environ.get("GSPLAT_BENCH_TRACE") == "1"  # diagnostics only: a synchronise + a line every 25 steps
+        worst = (0.0, -1)
         for i in range(K):
+            if trace:
+                h0 = time.perf_counter()
             step(8 + Wm + i)
+            if trace:
+                h1 = time.perf_counter() - h0
+                if h1 > worst[0]:
+                    worst = (h1, i)
             if trace and i % 25 == 24:
+                print("[trace] slowest single step so far (host time): %.3f ms at step %d" % (worst[0] * 1e3, worst[1]), file=sys.stderr)
                 torch.cuda.synchronize()
                 st = torch.cuda.memory_stats(dev)
                 print("[trace] leg tile_rect=%d step %d: %.4f ms/step so far, reserved %.0f MB, allocs %d, num_ooms %d, last count %s" % (
@@ -373,6 +391,7 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         dom = _lib.profile_collect().get(dominant, (0.0, 0))
         _lib.profile_enable(False)
         if world > 1:
