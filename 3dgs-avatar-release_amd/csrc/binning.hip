@@ -102,8 +102,11 @@ int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_
 #define TBK_THREADS 1024
 #define TBK_WAVES (TBK_THREADS / 64)
 #define TBK_BATCH 1024   // Gaussians per bitmap batch (32 words per tile)
-#define TBK_CHUNK 4096   // ranks filtered per trip (256 per wave, 4 per lane)
-#define TBK_BUF (TBK_BATCH + TBK_CHUNK)  // compacted Gaussians waiting for a batch: < 1024 carried + <= 4096 new
+#ifndef TBK_LPL
+#define TBK_LPL 2        // rank-list loads per lane and filter trip
+#endif
+#define TBK_CHUNK (TBK_THREADS * TBK_LPL)  // ranks filtered per trip (64 * TBK_LPL per wave)
+#define TBK_BUF (TBK_BATCH + TBK_CHUNK)    // compacted Gaussians waiting for a batch: < 1024 carried + <= TBK_CHUNK new
 
 // a match's rectangle clipped to the block, in block-local tile coordinates: lx (6 bits) | ly (2) | w - 1 (6) | h - 1 (2)
 __device__ __forceinline__ uint32_t pack_local_rect(int lx, int ly, int lw, int lh) {
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
                                                                  const uint32_t* __restrict__ seg_cnt,
                                                                  const uint2* __restrict__ ranges,
                                                                  uint32_t* __restrict__ point_list, const PairCount pc) {
-    __shared__ uint32_t m_id[TBK_BUF], m_rc[TBK_BUF];
+    __shared__ uint32_t m_id[TBK_BUF];
+    __shared__ unsigned short m_rc[TBK_BUF];
     __shared__ uint32_t bitmap[TB_TILES * BM_LD];  // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
     __shared__ uint32_t dst[TB_TILES];             // next free slot of every tile's list for this workgroup
     __shared__ uint32_t wcnt[TBK_WAVES];
@@ -271,11 +275,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
     int r0, r1;
     segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
-    uint4 e[4];
+    uint4 e[TBK_LPL];
     auto load_trip = [&](const int rb) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r = rb + wid * 256 + k * 64 + lane;  // a wave owns 256 consecutive ranks of the trip
+        for (int k = 0; k < TBK_LPL; k++) {
+            const int r = rb + wid * (64 * TBK_LPL) + k * 64 + lane;  // a wave owns 64 * TBK_LPL consecutive ranks of the trip
             e[k] = r < r1 ? ranklist[r] : make_uint4(0, 0, 0, 0);  // (tiles touched = 0: never a match)
         }
     };
@@ -346,11 +350,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     __syncthreads();
     for (int rb = r0; rb < r1 || count > 0;) {
         if (rb < r1) {
-            uint32_t rc[4], id[4];
-            unsigned long long bal[4];
-            int c[4], csum = 0;
+            uint32_t rc[TBK_LPL], id[TBK_LPL];
+            unsigned long long bal[TBK_LPL];
+            int c[TBK_LPL], csum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < TBK_LPL; k++) {
                 const bool h = block_hit(e[k], bx0, by0, bx1, by1, &rc[k]);
                 id[k] = e[k].x;
                 bal[k] = __ballot(h);
@@ -368,11 +372,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             }
             int slot0 = count + (int)woff;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < TBK_LPL; k++) {
                 if ((bal[k] >> lane) & 1ull) {
                     const int slot = slot0 + __popcll(bal[k] & lt_mask);
                     m_id[slot] = id[k];
-                    m_rc[slot] = rc[k];
+                    m_rc[slot] = (unsigned short)rc[k];
                 }
                 slot0 += c[k];
             }
@@ -384,17 +388,18 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         while (count >= TBK_BATCH || (last && count > 0)) {
             const int n = min(count, TBK_BATCH);
             process_batch(n);
-            const int rem = count - n;  // < 4096: at most four elements per thread move to the front
-            uint32_t cid[4], crc[4];
+            const int rem = count - n;  // < TBK_CHUNK: at most TBK_LPL elements per thread move to the front
+            uint32_t cid[TBK_LPL];
+            unsigned short crc[TBK_LPL];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < TBK_LPL; k++) {
                 const int i = tid + k * TBK_THREADS;
                 cid[k] = i < rem ? m_id[n + i] : 0u;
-                crc[k] = i < rem ? m_rc[n + i] : 0u;
+                crc[k] = i < rem ? m_rc[n + i] : (unsigned short)0;
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < TBK_LPL; k++) {
                 const int i = tid + k * TBK_THREADS;
                 if (i < rem) { m_id[i] = cid[k]; m_rc[i] = crc[k]; }
             }
