@@ -96,6 +96,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             const float4 a = *reinterpret_cast<const float4*>(sp);
             const float4 b = *reinterpret_cast<const float4*>(sp + 16);
             const float4 c = *reinterpret_cast<const float4*>(sp + 32);
+            // keep the whole 16 bytes of `c` one ds_read_b128 (4 LDS cycles): only r, g, b are used in the loop, and
+            // the 12-byte ds_read_b96 the compiler would pick takes 8 -- with it the loop needs 14 LDS cycles per entry
+            // and wave, 56 per four SIMDs against 52 cycles of VALU issue: the kernel was LDS-bound
+            asm volatile("" ::"v"(c.w));
             sp += 48;
             const float dx = a.x - pxf, dy = a.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2, evaluated exactly as the backward does

@@ -451,7 +451,9 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
     for k, v in got.items():
         w = want[names[k]].reshape(v.shape)
         _report(tag, "dL_d" + k, v, w)
-        _bulk_close(v, w, tol=2e-5, frac=2e-4, name=k + " " + tag, cap=GRAD_CAP)
+        # the north star's 1e-5 of the tensor maximum, for all but 2e-4 of the elements (measured: <= 1e-4 of them, the
+        # 99.99th percentile at ~2e-6 -- profiles/r02_parity_report.json), every element within GRAD_CAP
+        _bulk_close(v, w, tol=1e-5, frac=2e-4, name=k + " " + tag, cap=GRAD_CAP)
     culled = fw["radii"] == 0
     for k, v in got.items():
         assert (v[culled] == 0).all(), k
