@@ -7,65 +7,86 @@
 #include "gs_math.h"
 #include "blend.h"
 
-// Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous
-// span of pairs; each pair has four row slots (one per 8x8 quadrant of the tile), of which the
-// backward tile kernel wrote those whose ninth sum is not ROW_UNWRITTEN; fold with four DPP adds.  sums[i] = 12 floats.
+// Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous span of pairs,
+// TWO PAIRS PER STEP -- lane j of the group reads 16 bytes: pair slot j >> 3, quadrant (j >> 1) & 3, half j & 1 of the
+// 32-byte row -- so the eight lanes of a pair read one contiguous 128-byte line (a Gaussian-per-lane-group walk in which
+// every lane fetched whole rows touched 64 different lines per load instruction and ran at half the rate random lines can
+// be read at).  The backward tile kernel wrote only the rows whose ninth sum (the dense word array q8) is not
+// ROW_UNWRITTEN.  Fold with DPP adds.
+// sums[i] = 12 floats.
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ tiles,
-                                                             const uint4* __restrict__ q8,
+                                                             const uint32_t* __restrict__ q8,
                                                              const float4* __restrict__ qrows,
                                                              float4* __restrict__ sums) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t >> 4, j = t & 15;
-    float s[9];
-#pragma unroll
-    for (int c = 0; c < 9; c++) s[c] = 0.f;
+    const int ps = j >> 3, q = (j >> 1) & 3, h = j & 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a8 = 0.f;
     const bool in = i < P;
     if (in && radii[i] > 0) {
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
         const uint32_t tt = tiles[i];
-        for (uint32_t k = j; k < tt; k += 16) {
-            const uint4 w8 = q8[off + k];  // ninth sum of the pair's four rows, or ROW_UNWRITTEN
-            const uint32_t e8[4] = {w8.x, w8.y, w8.z, w8.w};
+        // The kernel is a chain of dependent load latencies (record -> marks -> rows) times the number of wave generations,
+        // not bandwidth: a trip covers 16 pairs of the Gaussian (8 per lane: most Gaussians need one trip), all marks of a
+        // trip are requested together, then all its rows, and the next trip's marks are requested before this trip's rows
+        // are added up.
+        constexpr int U = 8;
+        uint32_t mark[U], mark_n[U];
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                if (e8[qq] == ROW_UNWRITTEN) continue;
-                const size_t row = (size_t)(off + k) * 4 + qq;
-                const float4 e0 = qrows[row * 2];
-                const float4 e1 = qrows[row * 2 + 1];
-                s[0] += e0.x; s[1] += e0.y; s[2] += e0.z; s[3] += e0.w;
-                s[4] += e1.x; s[5] += e1.y; s[6] += e1.z; s[7] += e1.w;
-                s[8] += __uint_as_float(e8[qq]);
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = (uint32_t)ps + 2u * u;
+            mark[u] = k < tt ? q8[(size_t)(off + k) * 4 + q] : ROW_UNWRITTEN;
+        }
+        for (uint32_t k0 = (uint32_t)ps; k0 < tt; k0 += 2u * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t k = k0 + 2u * u;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mark[u] != ROW_UNWRITTEN) v[u] = qrows[((size_t)(off + k) * 4 + q) * 2 + h];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t k = k0 + 2u * U + 2u * u;
+                mark_n[u] = k < tt ? q8[(size_t)(off + k) * 4 + q] : ROW_UNWRITTEN;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w;
+                if (h == 0 && mark[u] != ROW_UNWRITTEN) a8 += __uint_as_float(mark[u]);
+                mark[u] = mark_n[u];
             }
         }
     }
+    // fold the two pair slots (lane ^ 8) and the four quadrants (lane ^ 2, lane ^ 4): lanes with h = 0 end up with the
+    // sums 0..3 and 8, lanes with h = 1 with the sums 4..7
+    float f[5] = {a0, a1, a2, a3, a8};
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        float v = s[c];
-        v += dpp_get<0xB1, 0xF>(v);   // lane ^ 1
-        v += dpp_get<0x4E, 0xF>(v);   // lane ^ 2
-        v += dpp_get<0x141, 0xF>(v);  // row_half_mirror: lane <-> 7 - lane inside each group of 8
-        v += dpp_get<0x140, 0xF>(v);  // row_mirror: lane <-> 15 - lane inside the row of 16
-        s[c] = v;
+    for (int c = 0; c < 5; c++) {
+        float v = f[c];
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        f[c] = v;
     }
     // The rows hold raw sums over pixels: (t dx, t dy, t dx^2, t dx dy, t dy^2, G dL/dalpha, w g_rgb) with
     // t = G dL/dalpha.  Apply what is constant per Gaussian: opacity (dL/dG = opacity dL/dalpha), the
     // conic combination giving dL/dmean2D (in the log2 domain the tile kernels work in), and the -1/2 of
     // dL/dconic.
-    if (in && j < 3) {
+    if (in && j < 2) {
         const float4 r0 = rec[(size_t)i * 3], r1 = rec[(size_t)i * 3 + 1];
         const float A2 = (-0.5f * LOG2E_F) * r0.z, B2 = -LOG2E_F * r0.w, C2 = (-0.5f * LOG2E_F) * r1.x, op = r1.y;
         const float il2 = 1.0f / LOG2E_F;
-        const float oa0 = op * s[0], oa1 = op * s[1];
-        s[0] = (2.f * A2 * oa0 + B2 * oa1) * il2;
-        s[1] = (2.f * C2 * oa1 + B2 * oa0) * il2;
-        s[2] *= -0.5f * op;
-        s[3] *= -0.5f * op;
-        s[4] *= -0.5f * op;
-        const float4 o = (j == 0) ? make_float4(s[0], s[1], s[2], s[3])
-                                  : (j == 1) ? make_float4(s[4], s[5], s[6], s[7]) : make_float4(s[8], 0.f, 0.f, 0.f);
-        sums[(size_t)i * 3 + j] = o;
+        if (j == 0) {
+            const float oa0 = op * f[0], oa1 = op * f[1];
+            sums[(size_t)i * 3] = make_float4((2.f * A2 * oa0 + B2 * oa1) * il2, (2.f * C2 * oa1 + B2 * oa0) * il2,
+                                              f[2] * (-0.5f * op), f[3] * (-0.5f * op));
+            sums[(size_t)i * 3 + 2] = make_float4(f[4], 0.f, 0.f, 0.f);
+        } else {
+            sums[(size_t)i * 3 + 1] = make_float4(f[0] * (-0.5f * op), f[1], f[2], f[3]);
+        }
     }
 }
 
@@ -308,7 +329,7 @@ int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const flo
                              const GsGrads& g, hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
     hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)(((size_t)a.P * 16 + 255) / 256)), dim3(256), 0, s, a.P, radii,
-                       reinterpret_cast<const float4*>(rec), tiles, reinterpret_cast<const uint4*>(q8),
+                       reinterpret_cast<const float4*>(rec), tiles, q8,
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
     const size_t lds = a.shs ? (size_t)256 * ((3 * a.M) | 1) * sizeof(float) : 0;
