@@ -99,7 +99,10 @@ int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_
 // ---------------------------------------------------------------------------------------------------------------
 // Tile lists.  Workgroup (block b of 64 x 4 tiles, segment g of the ranking), 1024 threads.
 // ---------------------------------------------------------------------------------------------------------------
-#define TBK_THREADS 1024
+#define TC_THREADS 1024   // counting pass
+#ifndef TBK_THREADS
+#define TBK_THREADS 1024  // writing pass
+#endif
 #define TBK_WAVES (TBK_THREADS / 64)
 #define TBK_BATCH 1024   // Gaussians per bitmap batch (32 words per tile)
 #ifndef TBK_LPL
@@ -133,8 +136,9 @@ __device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int b
 __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
                                                unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;
     const int nchunks = (P + 255) / 256;
-    const int per = (nchunks + TBK_THREADS - 1) / TBK_THREADS;  // consecutive chunks per thread
+    const int per = (nchunks + nthreads - 1) / nthreads;  // consecutive chunks per thread
     const int c0 = tid * per;
     unsigned long long mine = 0;
     for (int k = 0; k < per; k++)
@@ -145,12 +149,12 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
         const unsigned long long y = __shfl_up(x, d, 64);
         if (lane >= d) x += y;
     }
-    int* bounds = reinterpret_cast<int*>(scratch + TBK_WAVES);
+    int* bounds = reinterpret_cast<int*>(scratch + 16);
     if (lane == 63) scratch[wid] = x;
     if (tid == 0) { bounds[0] = nchunks; bounds[1] = nchunks; }
     __syncthreads();
     unsigned long long woff = 0, total = 0;
-    for (int w = 0; w < TBK_WAVES; w++) {
+    for (int w = 0; w < nwaves; w++) {
         const unsigned long long c = scratch[w];
         woff += w < wid ? c : 0ull;
         total += c;
@@ -183,7 +187,7 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
 // atomics per Gaussian instead of one per pair.  Workgroup (band of tile rows, segment); the band is the whole grid
 // unless the grid is too large for LDS.
 #define TC_CELLS 12288  // grid cells (4-byte) a workgroup holds
-__global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist,
+__global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist,
                                                                  const uint32_t* __restrict__ chunk_pairs, int P, int gx,
                                                                  int gy, int band_rows, int nbands, int nseg, int ntiles,
                                                                  uint32_t* __restrict__ seg_cnt) {
@@ -194,14 +198,14 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __
     const int y0b = band * band_rows, y1b = min(gy, y0b + band_rows);
     const int rows = y1b - y0b, ld = gx + 1;
     const int cells = (rows + 1) * ld;
-    for (int k = tid; k < cells; k += TBK_THREADS) grid[k] = 0;
+    for (int k = tid; k < cells; k += TC_THREADS) grid[k] = 0;
     int r0, r1;
     segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);  // (its barriers also cover the zeroing above)
-    for (int rb = r0 + tid; rb < r1; rb += 4 * TBK_THREADS) {
+    for (int rb = r0 + tid; rb < r1; rb += 4 * TC_THREADS) {
         uint4 e[4];  // four loads in flight per thread
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int r = rb + k * TBK_THREADS;
+            const int r = rb + k * TC_THREADS;
             e[k] = r < r1 ? ranklist[r] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __
     }
     __syncthreads();
     // prefix down the columns (thread per column), then along the rows (a wave per row, 64 cells per trip)
-    for (int x = tid; x < ld; x += TBK_THREADS) {
+    for (int x = tid; x < ld; x += TC_THREADS) {
         int acc = 0;
         for (int y = 0; y < rows; y++) {
             acc += grid[y * ld + x];
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_count_kernel(const uint4* __
         }
     }
     __syncthreads();
-    for (int y = wid; y < rows; y += TBK_WAVES) {
+    for (int y = wid; y < rows; y += (TC_THREADS / 64)) {
         int carry = 0;
         for (int x0 = 0; x0 < gx; x0 += 64) {
             const int x = x0 + lane;
@@ -603,7 +607,7 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P,
         if (band_rows > gy) band_rows = gy;
         const int nbands = (gy + band_rows - 1) / band_rows;
         StageScope sc_("tile_count", s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TBK_THREADS), 0, s, ranklist, chunk_pairs, P,
+        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, s, ranklist, chunk_pairs, P,
                            gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt);
         GS_LAUNCH_CHECK("tile_count", debug, s);
     }

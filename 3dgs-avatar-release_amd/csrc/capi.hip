@@ -17,6 +17,7 @@ static void tune_defaults() {
     if (g_tune_init) return;
     g_tune_init = true;
     g_tune[GS_TUNE_XCD_MAP].store(1);
+    g_tune[GS_TUNE_DEPTH_SORT].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -131,7 +132,8 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         sort_totals_region((uint32_t*)(g + L.hist), a->P, 32, &zt.ptr, &zt.words);
         { StageScope sc_("preprocess", s);
         rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
-                               (uint32_t*)(g + L.clamped), k0, v0, radii, (uint32_t*)(g + L.wsum), zt, s); }
+                               (uint32_t*)(g + L.clamped), k0, v0, radii, (uint32_t*)(g + L.wsum), (uint32_t*)(g + L.wkmin),
+                               (uint32_t*)(g + L.wkmax), zt, s); }
         if (rc != GS_OK) return rc;
         // pair numbering (Gaussian-major, index order) and the pair count: needs nothing of the depth sort, so the
         // count is on its way to the host while the sort runs
@@ -139,11 +141,18 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         rc = launch_first_pair((const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
                                a->P, a->debug, s); }
         if (rc != GS_OK) return rc;
-        // stable sort by depth bits: ties keep ascending Gaussian index (the reference's tie order)
+        // (depth key, index) order: ties keep ascending Gaussian index (the reference's tie order); the ranking ends in v0
         { StageScope sc_("depth_sort", s);
-        rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s); }
+        if (gs_tune_get(GS_TUNE_DEPTH_SORT)) {
+            const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_tot),
+                                    (uint32_t*)(g + L.ds_loc), (uint32_t*)(g + L.ds_grp), (uint32_t*)(g + L.ds_range), L.ds_nb,
+                                    L.ds_blocks};
+            rc = launch_depth_sort(k0, (const uint32_t*)(g + L.wkmin), (const uint32_t*)(g + L.wkmax), L.nwaves, a->P, st, v0,
+                                   a->debug, s);
+        } else {
+            rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s);  // 4 passes: ends in (k0, v0)
+        } }
         if (rc != GS_OK) return rc;
-        // 4 passes -> the sorted index ends in (k0, v0)
         { StageScope sc_("rank_list", s);
         rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist),
                               (uint32_t*)(g + L.chunk_pairs), a->P, a->debug, s); }
@@ -607,6 +616,7 @@ int gs_tuning(const char* name, int value) {
     if (!name) return GS_E_BAD_ARG;
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix
     return GS_E_BAD_ARG;
 }
 

@@ -26,9 +26,17 @@ static inline size_t sort_table_words(size_t n) {
 }
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
+#define DS_ITEMS 1024  // keys per workgroup in the counting / scattering passes of the bucket depth sort
+// depth buckets for P Gaussians: ~128 per bucket for a uniform spread, a multiple of 64, 256 ... 4096
+static inline int ds_buckets(int P) {
+    int nb = (P / 128 + 63) / 64 * 64;
+    return nb < 256 ? 256 : (nb > 4096 ? 4096 : nb);
+}
+
 struct GeomLayout {
-    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, hist, count, total;
-    int nblk_sort, nwaves;
+    size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, wkmin, wkmax, hist, count,
+        ds_tmp, ds_cnt, ds_tot, ds_loc, ds_grp, ds_range, total;
+    int nblk_sort, nwaves, ds_nb, ds_blocks;
 };
 static inline GeomLayout geom_layout(int P) {
     GeomLayout L;
@@ -48,8 +56,19 @@ static inline GeomLayout geom_layout(int P) {
     L.ranklist = take(n * 16);               // (index, rect min, rect size, tiles touched) in depth-rank order
     L.chunk_pairs = take(((n + 255) / 256) * 4);  // tiles touched per chunk of 256 consecutive ranks
     L.wsum = take((size_t)L.nwaves * 4);     // tiles touched per preprocess wave
+    L.wkmin = take((size_t)L.nwaves * 4);    // smallest / largest depth key of the wave's Gaussians that touch a tile
+    L.wkmax = take((size_t)L.nwaves * 4);
     L.hist = take(sort_table_words(n) * 4);
     L.count = take(64);
+    // bucket depth sort (depth_sort.hip): DS_NB(P) depth buckets + one for the Gaussians that touch no tile
+    L.ds_nb = ds_buckets(P);
+    L.ds_blocks = (int)((n + DS_ITEMS - 1) / DS_ITEMS);
+    L.ds_tmp = take(n * 8);                                        // (key << 32 | index), bucket after bucket
+    L.ds_cnt = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // [block][bucket] counts, then their prefix over the blocks
+    L.ds_tot = take((size_t)(L.ds_nb + 1) * 4);
+    L.ds_loc = take((size_t)(L.ds_nb + 1) * 4);
+    L.ds_grp = take((size_t)((L.ds_nb + 1 + 63) / 64) * 4);
+    L.ds_range = take(16);
     L.total = o;
     return L;
 }
@@ -72,7 +91,9 @@ static inline BinLayout bin_layout(int64_t D) {
 // SEGMENTS of the depth-ranked Gaussian list; workgroup (block, segment) counts / writes the pairs of its segment's
 // Gaussians with its block's tiles (binning.hip).
 #define TB_W 64
-#define TB_H 4
+#ifndef TB_H
+#define TB_H 4   // 1, 2 or 4 (the clipped rectangle's rows are packed in 2 bits)
+#endif
 #define TB_TILES (TB_W * TB_H)
 #define TB_MAX_SEG 64
 struct BinGrid { int nbx, nby, nblocks, nseg_max; };
@@ -81,7 +102,10 @@ static inline BinGrid bin_grid(int gx, int gy) {
     G.nbx = (gx + TB_W - 1) / TB_W;
     G.nby = (gy + TB_H - 1) / TB_H;
     G.nblocks = G.nbx * G.nby;
-    int s = (512 + G.nblocks - 1) / G.nblocks;  // about two workgroups per CU over the chip
+#ifndef TB_TARGET_WGS
+#define TB_TARGET_WGS 512  // about two workgroups per CU over the chip
+#endif
+    int s = (TB_TARGET_WGS + G.nblocks - 1) / G.nblocks;
     G.nseg_max = s < 1 ? 1 : (s > TB_MAX_SEG ? TB_MAX_SEG : s);
     return G;
 }
@@ -151,7 +175,7 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
 
 // Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
 int gs_tune_get(int key);
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_COUNT = 8 };
 
 // Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
 // with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
@@ -179,8 +203,12 @@ struct StageScope {
 // Stage launchers (each enqueues on `s`, returns GS_OK / GS_E_HIP)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, ZeroJob zero,
-                      hipStream_t s);
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
+                      uint32_t* wave_kmax, ZeroJob zero, hipStream_t s);
+// bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
+struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *tot, *loc, *grp, *range; int nb, blocks; };
+int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
+                      DepthSortState st, uint32_t* sorted_idx, int debug, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);

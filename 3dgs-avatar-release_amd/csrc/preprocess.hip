@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy, int tile_rect,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii,
-    uint32_t* __restrict__ wave_tiles, ZeroJob zero) {
+    uint32_t* __restrict__ wave_tiles, uint32_t* __restrict__ wave_kmin, uint32_t* __restrict__ wave_kmax, ZeroJob zero) {
     zero_job(zero);  // the depth sort's digit totals (saves a fill launch)
     // threads past the end (last workgroup only) redo Gaussian P - 1 and store nothing: every lane of every wave reaches
     // the wave-level sum of tiles touched at the end
@@ -140,15 +140,27 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
     // tiles touched by this wave's 64 Gaussians: the first level of the prefix sum that numbers the (tile, Gaussian)
     // pairs (first_pair_kernel), saving its reduction launch
+    // ... and the range of this wave's depth keys (Gaussians that touch a tile only): the bucket depth sort maps keys to
+    // buckets linearly between the frame's smallest and largest key
     uint32_t wsum = live ? tt : 0u;
+    const bool keyed = live && tt != 0u;
+    uint32_t kmin = keyed ? __float_as_uint(depth) : 0xFFFFFFFFu, kmax = keyed ? __float_as_uint(depth) : 0u;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
-    if ((threadIdx.x & 63) == 0) wave_tiles[gi >> 6] = wsum;
+    for (int d = 32; d >= 1; d >>= 1) {
+        wsum += __shfl_xor(wsum, d, 64);
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wave_tiles[gi >> 6] = wsum;
+        wave_kmin[gi >> 6] = kmin;
+        wave_kmax[gi >> 6] = kmax;
+    }
 }
 
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
-                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, ZeroJob zero,
-                      hipStream_t s) {
+                      uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
+                      uint32_t* wave_kmax, ZeroJob zero, hipStream_t s) {
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
     const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
     const int blocks = (a.P + 255) / 256;
@@ -157,7 +169,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
                        a.tile_rect,
-                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, wave_tiles, zero);
+                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, wave_tiles, wave_kmin, wave_kmax, zero);
     GS_LAUNCH_CHECK("preprocess", a.debug, s);
     return GS_OK;
 }

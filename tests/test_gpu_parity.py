@@ -298,6 +298,48 @@ def test_knn_at_the_reference_sizes_every_search_variant(oracle):
         assert np.array_equal(got3.view(np.uint32), want3.astype(np.float32).view(np.uint32)), n
 
 
+@pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths"])
+def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
+    """The depth ranking is a bucket sort over the frame's key range (depth_sort.hip): ~128 keys per bucket when the
+    depths are evenly spread.  Uneven spreads must give the same bits through its other paths: a bucket beyond 4096 keys
+    (second launch, 128 KB of LDS), beyond 16384 (global-memory network), equal keys (ties in ascending index order), a
+    key range stretched by far outliers.  Checked: the ranking itself ((depth bits, index) ascending over the Gaussians
+    that touch a tile) and the tile lists against the oracle, bit for bit."""
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n, W, H = 24000, 256, 192
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=0, seed=61, scale_mul=0.6)
+    g = torch.Generator().manual_seed(7)
+    if case == "one-depth":
+        cloud.xyz[:, 2] = 0.25           # every view-space depth is exactly 3.25: one bucket of 24000 equal keys
+    elif case == "half-one-depth":
+        cloud.xyz[::2, 2] = -0.5         # 12000 equal keys (a bucket beyond the small LDS size) among spread ones
+    elif case == "far-outliers":
+        cloud.xyz[:40, 2] = torch.empty(40).uniform_(1e4, 1e6, generator=g)  # the key range spans 18 binades
+        cloud.xyz[40:, 2] = cloud.xyz[40:, 2] * 0.05                         # ... and the rest sits in 2 % of it
+    else:
+        cloud.xyz[:, 2] = torch.where(torch.arange(n) % 3 == 0, torch.tensor(0.5), torch.tensor(-0.25))
+    bg = (0.0, 0.0, 0.0)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    fw = oracle.forward(helpers.oracle_scene(cloud, cam, bg=bg))
+    assert np.array_equal(st["radii"], fw["radii"]) and st["D"] == fw["binning"]["D"] and st["D"] > 0
+    tt = st["geom"]["tiles_touched"]
+    order = st["geom"]["sorted_idx"].astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(n))  # a permutation
+    nvis = int((tt > 0).sum())
+    head = order[:nvis]
+    assert (tt[head] > 0).all() and (tt[order[nvis:]] == 0).all()  # Gaussians that touch no tile come last
+    dbits = st["geom"]["depths"].view(np.uint32)[head].astype(np.int64)
+    assert (np.diff(dbits) >= 0).all()
+    tie = np.diff(dbits) == 0
+    assert (np.diff(head)[tie] > 0).all()
+    assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"])
+    nz = fw["binning"]["ranges"][:, 1] > fw["binning"]["ranges"][:, 0]
+    assert np.array_equal(st["image"]["ranges"][nz], fw["binning"]["ranges"][nz])
+    _bulk_close(st["color"], fw["color"], frac=1e-4, name="color " + case)
+
+
 def test_render_harness_train_step_config_shapes(oracle):
     """The render()-shaped harness on the reference's default input combination
     (colors_precomp + cov3D_precomp, two rasterizer calls per step) against the oracle."""
