@@ -144,7 +144,8 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         // (depth key, index) order: ties keep ascending Gaussian index (the reference's tie order); the ranking ends in v0
         { StageScope sc_("depth_sort", s);
         if (gs_tune_get(GS_TUNE_DEPTH_SORT)) {
-            const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_tot),
+            const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_pre),
+                                    (uint32_t*)(g + L.ds_tot),
                                     (uint32_t*)(g + L.ds_loc), (uint32_t*)(g + L.ds_grp), (uint32_t*)(g + L.ds_range), L.ds_nb,
                                     L.ds_blocks};
             rc = launch_depth_sort(k0, (const uint32_t*)(g + L.wkmin), (const uint32_t*)(g + L.wkmax), L.nwaves, a->P, st, v0,

@@ -26,7 +26,7 @@ static inline size_t sort_table_words(size_t n) {
 }
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
-#define DS_ITEMS 1024  // keys per workgroup in the counting / scattering passes of the bucket depth sort
+#define DS_ITEMS 2048  // keys per workgroup in the counting / scattering passes of the bucket depth sort
 // depth buckets for P Gaussians: ~128 per bucket for a uniform spread, a multiple of 64, 256 ... 4096
 static inline int ds_buckets(int P) {
     int nb = (P / 128 + 63) / 64 * 64;
@@ -35,7 +35,7 @@ static inline int ds_buckets(int P) {
 
 struct GeomLayout {
     size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, wkmin, wkmax, hist, count,
-        ds_tmp, ds_cnt, ds_tot, ds_loc, ds_grp, ds_range, total;
+        ds_tmp, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, total;
     int nblk_sort, nwaves, ds_nb, ds_blocks;
 };
 static inline GeomLayout geom_layout(int P) {
@@ -64,7 +64,8 @@ static inline GeomLayout geom_layout(int P) {
     L.ds_nb = ds_buckets(P);
     L.ds_blocks = (int)((n + DS_ITEMS - 1) / DS_ITEMS);
     L.ds_tmp = take(n * 8);                                        // (key << 32 | index), bucket after bucket
-    L.ds_cnt = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // [block][bucket] counts, then their prefix over the blocks
+    L.ds_cnt = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // [block][bucket] counts ...
+    L.ds_pre = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // ... and their exclusive prefix over the blocks
     L.ds_tot = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_loc = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_grp = take((size_t)((L.ds_nb + 1 + 63) / 64) * 4);
@@ -206,7 +207,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
                       uint32_t* wave_kmax, ZeroJob zero, hipStream_t s);
 // bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
-struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *tot, *loc, *grp, *range; int nb, blocks; };
+struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range; int nb, blocks; };
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, uint32_t* sorted_idx, int debug, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,

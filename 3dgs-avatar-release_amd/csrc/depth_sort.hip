@@ -14,8 +14,7 @@
 #include "common.h"
 
 #define DS_THREADS 256
-#define DS_CAP 4096        // composites a workgroup sorts in LDS (32 KB) ...
-#define DS_CAP_BIG 16384   // ... and in the second launch, for unevenly spread depths (128 KB)
+#define DS_CAP_BIG 16384   // composites a 256-thread workgroup sorts in LDS (128 KB): second launch, for unevenly spread depths
 
 __device__ __forceinline__ uint32_t ds_bucket_of(uint32_t key, uint32_t kmin, unsigned long long span, int nb) {
     // span = kmax - kmin + 1 (>= 1); keys outside [kmin, kmax] only for Gaussians that touch no tile (0xFFFFFFFF)
@@ -51,7 +50,8 @@ __device__ __forceinline__ void ds_key_range(const uint32_t* __restrict__ wave_k
 __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ wave_kmin,
                                                               const uint32_t* __restrict__ wave_kmax, int nwaves, int P,
-                                                              int nb, uint32_t* __restrict__ cnt) {
+                                                              int nb, uint32_t* __restrict__ cnt,
+                                                              uint32_t* __restrict__ krange) {
     extern __shared__ uint32_t s_hist[];  // nb + 1 counters + 8 words
     uint32_t* s_red = s_hist + nb + 1;
     const int tid = threadIdx.x;
@@ -65,6 +65,11 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
     uint32_t kmin;
     unsigned long long span;
     ds_key_range(wave_kmin, wave_kmax, nwaves, s_red, &kmin, &span);  // (its barriers also cover the zeroing)
+    if (blockIdx.x == 0 && tid == 0) {  // for the scattering pass: it need not reduce the waves' ranges again
+        krange[0] = kmin;
+        krange[1] = (uint32_t)span;
+        krange[2] = (uint32_t)(span >> 32);
+    }
 #pragma unroll
     for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
@@ -76,20 +81,21 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
 
 // One wave per group of 64 buckets.  Per bucket: the workgroups' counts -> their exclusive prefix (in place) and the
 // bucket's total; per group: the buckets' exclusive prefix inside the group and the group's total.
-__global__ __launch_bounds__(64) void ds_prefix_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ tot,
-                                                       uint32_t* __restrict__ loc, uint32_t* __restrict__ grp, int nbp,
-                                                       int blocks) {
+__global__ __launch_bounds__(64) void ds_prefix_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ pre,
+                                                       uint32_t* __restrict__ tot, uint32_t* __restrict__ loc,
+                                                       uint32_t* __restrict__ grp, int nbp, int blocks) {
     const int lane = threadIdx.x;
     const int b = blockIdx.x * 64 + lane;
     uint32_t acc = 0;
     if (b < nbp) {
-        for (int g0 = 0; g0 < blocks; g0 += 8) {
-            uint32_t v[8];
+        // (input and output are different arrays: the loads of all trips can be in flight together)
+        for (int g0 = 0; g0 < blocks; g0 += 16) {
+            uint32_t v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (g0 + u < blocks) ? cnt[(size_t)(g0 + u) * nbp + b] : 0u;
+            for (int u = 0; u < 16; u++) v[u] = (g0 + u < blocks) ? cnt[(size_t)(g0 + u) * nbp + b] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (g0 + u < blocks) cnt[(size_t)(g0 + u) * nbp + b] = acc;
+            for (int u = 0; u < 16; u++) {
+                if (g0 + u < blocks) pre[(size_t)(g0 + u) * nbp + b] = acc;
                 acc += v[u];
             }
         }
@@ -130,8 +136,7 @@ __device__ __forceinline__ void ds_bucket_bases(const uint32_t* __restrict__ loc
 }
 
 __global__ __launch_bounds__(DS_THREADS) void ds_scatter_kernel(const uint32_t* __restrict__ keys,
-                                                                const uint32_t* __restrict__ wave_kmin,
-                                                                const uint32_t* __restrict__ wave_kmax, int nwaves, int P,
+                                                                const uint32_t* __restrict__ krange, int P,
                                                                 int nb, const uint32_t* __restrict__ cnt,
                                                                 const uint32_t* __restrict__ loc,
                                                                 const uint32_t* __restrict__ grp,
@@ -140,7 +145,6 @@ __global__ __launch_bounds__(DS_THREADS) void ds_scatter_kernel(const uint32_t* 
     const int nbp = nb + 1;
     uint32_t* s_next = s_mem;
     uint32_t* s_grp = s_mem + nbp;
-    uint32_t* s_red = s_grp + 66;
     const int tid = threadIdx.x;
     uint32_t k[DS_ITEMS / DS_THREADS];
 #pragma unroll
@@ -148,9 +152,8 @@ __global__ __launch_bounds__(DS_THREADS) void ds_scatter_kernel(const uint32_t* 
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
         k[u] = i < P ? keys[i] : 0u;
     }
-    uint32_t kmin;
-    unsigned long long span;
-    ds_key_range(wave_kmin, wave_kmax, nwaves, s_red, &kmin, &span);
+    const uint32_t kmin = krange[0];
+    const unsigned long long span = (unsigned long long)krange[1] | ((unsigned long long)krange[2] << 32);
     ds_bucket_bases(loc, grp, nbp, s_grp, s_next);
     for (int b = tid; b < nbp; b += DS_THREADS) s_next[b] += cnt[(size_t)blockIdx.x * nbp + b];  // + the workgroups before this one
     __syncthreads();
@@ -196,6 +199,64 @@ __device__ __forceinline__ void ds_bitonic(const long long n, LOAD load, STORE s
     }
 }
 
+// One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~128
+// per bucket): the network runs in LDS without workgroup barriers -- a wave's LDS operations execute in order.
+#define DS_WAVE_CAP 1024
+__global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned long long* __restrict__ tmp,
+                                                                 const uint32_t* __restrict__ tot,
+                                                                 const uint32_t* __restrict__ loc,
+                                                                 const uint32_t* __restrict__ grp, int nb,
+                                                                 uint32_t* __restrict__ sorted_idx) {
+    __shared__ unsigned long long s[DS_WAVE_CAP];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;  // bucket; bucket nb holds the Gaussians that touch no tile
+    const int n = (int)tot[b];
+    if (n == 0 || (n > DS_WAVE_CAP && b != nb)) return;  // (larger buckets: ds_bucket_sort_kernel)
+    uint32_t part = 0;
+    for (int q = lane; q < (b >> 6); q += 64) part += grp[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t start = part + loc[b];
+    const unsigned long long* seg = tmp + start;
+    if (b == nb) {
+        // no order needed among the Gaussians that touch no tile (every later stage skips them)
+        for (int i = lane; i < n; i += 64) sorted_idx[start + i] = (uint32_t)seg[i];
+        return;
+    }
+    // between two steps: nothing may be kept in registers or moved across (the LDS itself keeps a wave's accesses in order)
+    auto step_done = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int i = lane; i < n; i += 64) s[i] = seg[i];
+    step_done();
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    const int half = n_pad >> 1;
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int t = lane; t < half; t += 64) {  // flip step (see ds_bitonic)
+            const int blk = t / (k >> 1), off = t % (k >> 1);
+            const int i = blk * k + off, p = blk * k + (k - 1 - off);
+            if (p < n) {
+                const unsigned long long a = s[i], c = s[p];
+                if (a > c) { s[i] = c; s[p] = a; }
+            }
+        }
+        step_done();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int t = lane; t < half; t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i + j;
+                if (p < n) {
+                    const unsigned long long a = s[i], c = s[p];
+                    if (a > c) { s[i] = c; s[p] = a; }
+                }
+            }
+            step_done();
+        }
+    }
+    for (int i = lane; i < n; i += 64) sorted_idx[start + i] = (uint32_t)s[i];
+}
+
 // One workgroup per bucket.  Buckets of [n_lo, n_hi] composites are handled by this launch (the others by the launch of
 // the other LDS size); at most CAP of them are sorted in LDS, more in global memory.
 template <int CAP>
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned lon
     const int tid = threadIdx.x;
     const int b = blockIdx.x;  // bucket; bucket nb holds the Gaussians that touch no tile
     const int n = (int)tot[b];
-    if (n < n_lo || (n_lo == 1 && n > CAP)) return;  // (workgroup-uniform) not this launch's bucket
+    if (n < n_lo || b == nb) return;  // (workgroup-uniform) not this launch's bucket
     // first slot of this bucket: the groups before its own + its prefix inside the group
     {
         const int g = b >> 6;
@@ -249,22 +310,22 @@ __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned lon
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, uint32_t* sorted_idx, int debug, hipStream_t s) {
     const int nbp = st.nb + 1;
-    const size_t lds_count = (size_t)(nbp + 8) * 4, lds_scatter = (size_t)(nbp + 66 + 8) * 4;
+    const size_t lds_count = (size_t)(nbp + 8) * 4, lds_scatter = (size_t)(nbp + 66) * 4;
     hipLaunchKernelGGL(ds_count_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_count, s, keys, wave_kmin, wave_kmax, nwaves, P,
-                       st.nb, st.cnt);
+                       st.nb, st.cnt, st.range);
     GS_LAUNCH_CHECK("depth_sort.count", debug, s);
-    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(64), 0, s, st.cnt, st.tot, st.loc, st.grp, nbp, st.blocks);
+    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(64), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp, nbp,
+                       st.blocks);
     GS_LAUNCH_CHECK("depth_sort.prefix", debug, s);
-    hipLaunchKernelGGL(ds_scatter_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_scatter, s, keys, wave_kmin, wave_kmax, nwaves,
-                       P, st.nb, st.cnt, st.loc, st.grp, st.tmp);
+    hipLaunchKernelGGL(ds_scatter_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_scatter, s, keys, st.range, P, st.nb, st.pre,
+                       st.loc, st.grp, st.tmp);
     GS_LAUNCH_CHECK("depth_sort.scatter", debug, s);
-    // buckets of up to DS_CAP composites (all of them unless the depths are very unevenly spread: ~128 on average), then
-    // the larger ones with 128 KB of LDS per workgroup (its workgroups leave at once when there is none)
-    hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP>, dim3(nbp), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, 1,
-                       sorted_idx);
+    // a wave per bucket for the buckets of up to DS_WAVE_CAP composites (all of them unless the depths are very unevenly
+    // spread), then the larger ones with 128 KB of LDS per workgroup (its workgroups leave at once when there is none)
+    hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(nbp), dim3(64), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, sorted_idx);
     GS_LAUNCH_CHECK("depth_sort.buckets", debug, s);
     hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP_BIG>, dim3(nbp), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp,
-                       st.nb, DS_CAP + 1, sorted_idx);
+                       st.nb, DS_WAVE_CAP + 1, sorted_idx);
     GS_LAUNCH_CHECK("depth_sort.big_buckets", debug, s);
     return GS_OK;
 }
