@@ -180,6 +180,17 @@ def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotatio
     return a
 
 
+def _dump_snapshot(path, raster_settings, tensors):
+    """What upstream's debug mode does when the native call raises: the call's arguments, copied to the CPU, are saved
+    with torch.save (upstream: snapshot_fw.dump / snapshot_bw.dump in the working directory)."""
+    try:
+        cpu = [t.detach().cpu().clone() if isinstance(t, torch.Tensor) else t for t in tensors]
+        settings = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in raster_settings._asdict().items()}
+        torch.save({"settings": settings, "tensors": cpu}, path)
+    except Exception:  # the dump is best effort: the original error is what the caller must see
+        pass
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, with_opacity=False):
     """(color, radii), as upstream.  with_opacity=True (an extension; see GaussianRasterizer.forward) adds the
@@ -193,6 +204,22 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, with_opacity=False):
+        if not raster_settings.debug:
+            return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                                cov3Ds_precomp, raster_settings, with_opacity)
+        # upstream's debug mode: the arguments are kept aside and written to snapshot_fw.dump if the native call fails
+        args = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        try:
+            return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                                cov3Ds_precomp, raster_settings, with_opacity)
+        except Exception:
+            _dump_snapshot("snapshot_fw.dump", raster_settings, args)
+            print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise
+
+    @staticmethod
+    def _forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                 raster_settings, with_opacity=False):
         ctx.with_opacity = bool(with_opacity)
         # outputs nothing downstream differentiates (always: radii) arrive as None in backward instead of as freshly
         # filled zero tensors -- one fill launch over P ints per step otherwise
@@ -303,6 +330,17 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
+        if not ctx.raster_settings.debug:
+            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity)
+        try:
+            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity)
+        except Exception:
+            _dump_snapshot("snapshot_bw.dump", ctx.raster_settings, tuple(ctx.saved_tensors[:8]) + (grad_out_color,))
+            print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise
+
+    @staticmethod
+    def _backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
         L = _lib.load()
         entry = getattr(ctx, "geom_entry", None)
         if entry is not None:  # a render after this backward (e.g. after an optimiser step) must not meet this state

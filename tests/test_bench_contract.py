@@ -24,9 +24,19 @@ def test_algorithmic_bytes_follow_the_survey_worked_example():
 
 
 def test_committed_bench_lines_carry_the_contract_fields():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_config3_bench.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_v*_config3_bench.json")))
     assert lines
     d = json.load(open(lines[-1]))
+    if os.path.basename(lines[-1]).startswith("r02"):
+        # round 2: the reference's own binning timed in the same run, measured traffic and the VALU ceiling
+        u = d["upstream_rect"]
+        assert u["tile_rect"] == 0 and u["num_rendered"] > d["config"]["num_rendered"] and u["value"] > 0
+        assert d["config"]["tile_rect"] == 1 and d["config"]["ranks"] == d["n_gpus"]
+        r = d["roofline"]
+        assert r["traffic"] and r["traffic_over_algorithmic"] == round(r["traffic"] / r["algorithmic_bytes"], 3)
+        assert "rocprofv3" in r["traffic_source"]
+        for k in ("render_fwd", "render_bwd"):
+            assert 0 < r["valu"][k]["issue_slot_util"] < 1 and r["valu"][k]["insts_per_launch"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -43,3 +53,39 @@ def test_committed_bench_lines_carry_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_gpus_flag_starts_the_ranks_itself_and_refuses_a_mismatch(monkeypatch):
+    """`python bench.py --gpus N` with no launcher starts N ranks as a CHILD `torch.distributed.run` on the same file
+    (round 1 parsed the flag and ran one rank); under a launcher whose WORLD_SIZE differs from --gpus it exits non-zero
+    instead of printing a mislabeled line.  No GPU is touched by either path."""
+    import subprocess
+    import sys
+
+    import bench
+    import pytest
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert e.value.code == 7  # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # launched under a launcher with another world size: refuse
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4"])
+    assert e.value.code == 2

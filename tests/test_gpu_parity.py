@@ -235,6 +235,30 @@ def test_argument_validation_matches_upstream_messages():
              rotations=cloud.rotations.to(dev))
 
 
+def test_debug_mode_dumps_the_arguments_when_the_native_call_fails(tmp_path, monkeypatch):
+    """pipe.debug (configs/config.yaml:92, forwarded at gaussian_renderer/__init__.py:97): upstream's wrapper keeps the
+    call's arguments aside and writes snapshot_fw.dump when the native forward raises.  Same here."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cloud, cam = helpers.cloud_and_camera(16, 32, 32, sh_degree=3, seed=1)
+    monkeypatch.chdir(tmp_path)
+    rast = GaussianRasterizer(_settings(cam, cloud, (0, 0, 0), dev, debug=True))
+    bad_shs = torch.zeros(16, 17, 3, device=dev)  # 17 coefficients per channel: rejected by the library (M <= 16)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        rast(means3D=cloud.xyz.to(dev), means2D=cloud.xyz.to(dev), opacities=cloud.opacity.to(dev), shs=bad_shs,
+             scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert dump["settings"]["image_width"] == 32 and dump["settings"]["debug"] is True
+    assert dump["tensors"][2].shape == (16, 17, 3) and dump["tensors"][0].device.type == "cpu"
+    # without debug: same error, no dump
+    (tmp_path / "snapshot_fw.dump").unlink()
+    rast = GaussianRasterizer(_settings(cam, cloud, (0, 0, 0), dev, debug=False))
+    with pytest.raises(RuntimeError):
+        rast(means3D=cloud.xyz.to(dev), means2D=cloud.xyz.to(dev), opacities=cloud.opacity.to(dev), shs=bad_shs,
+             scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    assert not (tmp_path / "snapshot_fw.dump").exists()
+
+
 def test_mark_visible(oracle):
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device("cuda:0")
