@@ -125,6 +125,16 @@ def release_shared_geometry():
 _last_count = {}  # (device, P, W, H) -> num_rendered of the previous call: a sizing hint only
 
 
+def _capacity_for(count):
+    """Pairs to carve the binning state (and the backward scratch) for, given the previous frame's pair count: 1/8 of
+    slack, rounded UP to a multiple of 2^(bit length - 5) -- steps of 3-6 %.  Consecutive frames of a sequence, whose
+    counts drift by a fraction of a percent, then ask the caching allocator for the SAME sizes frame after frame (the
+    scratch is gigabytes at 500k Gaussians / 2048^2: a new size every frame makes it split and re-allocate blocks)."""
+    want = count + count // 8
+    step = 1 << max(want.bit_length() - 5, 0)
+    return (want + step - 1) // step * step
+
+
 def _pinned_count(device):
     """A per-thread, per-device pinned int64 the library copies num_rendered into."""
     cache = getattr(_tls, "pinned", None)
@@ -282,7 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # the GPU never idles for it.  Only when the count exceeds the capacity (or there is no estimate yet)
             # does control come back here to allocate and run phase 2 again.
             guess = _last_count.get((dev.index, P, W, H), 0)
-            capacity = guess + guess // 8 if (guess and _SPECULATE) else 0
+            capacity = _capacity_for(guess) if (guess and _SPECULATE) else 0
             bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H) if capacity else 0
             binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if capacity else None
             nr = ctypes.c_int64(0)
