@@ -471,7 +471,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
-            fill.ptr[k] = ones;
+            if (fill.stream) store_stream(&fill.ptr[k], ones); else fill.ptr[k] = ones;
         return;
     }
     constexpr int PER = 32;

@@ -18,6 +18,7 @@ static void tune_defaults() {
     g_tune_init = true;
     g_tune[GS_TUNE_XCD_MAP].store(1);
     g_tune[GS_TUNE_DEPTH_SORT].store(1);
+    g_tune[GS_TUNE_NT_STORES].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -135,29 +136,35 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
                                (uint32_t*)(g + L.clamped), k0, v0, radii, (uint32_t*)(g + L.wsum), (uint32_t*)(g + L.wkmin),
                                (uint32_t*)(g + L.wkmax), zt, s); }
         if (rc != GS_OK) return rc;
-        // pair numbering (Gaussian-major, index order) and the pair count: needs nothing of the depth sort, so the
-        // count is on its way to the host while the sort runs
-        { StageScope sc_("pair_scan", s);
-        rc = launch_first_pair((const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
-                               a->P, a->debug, s); }
-        if (rc != GS_OK) return rc;
-        // (depth key, index) order: ties keep ascending Gaussian index (the reference's tie order); the ranking ends in v0
-        { StageScope sc_("depth_sort", s);
+        // pair numbering (Gaussian-major, index order) and the pair count need nothing of the depth sort, so the count is
+        // on its way to the host while the sort runs; (depth key, index) order: ties keep ascending Gaussian index (the
+        // reference's tie order); the ranking ends in v0 and, with what binning needs of every Gaussian, in the rank list
         if (gs_tune_get(GS_TUNE_DEPTH_SORT)) {
+            StageScope sc_("depth_sort", s);  // the numbering rides in its first launch, the rank list in its last ones
             const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_pre),
                                     (uint32_t*)(g + L.ds_tot),
                                     (uint32_t*)(g + L.ds_loc), (uint32_t*)(g + L.ds_grp), (uint32_t*)(g + L.ds_range), L.ds_nb,
                                     L.ds_blocks};
-            rc = launch_depth_sort(k0, (const uint32_t*)(g + L.wkmin), (const uint32_t*)(g + L.wkmax), L.nwaves, a->P, st, v0,
+            const PairNumbering pn{(const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
+                                   (uint32_t*)(g + L.chunk_pairs), (a->P + 255) / 256};
+            const RankOut ro{(const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), v0, (uint4*)(g + L.ranklist),
+                             (uint32_t*)(g + L.chunk_pairs)};
+            rc = launch_depth_sort(k0, (const uint32_t*)(g + L.wkmin), (const uint32_t*)(g + L.wkmax), L.nwaves, a->P, st, pn, ro,
                                    a->debug, s);
-        } else {
-            rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s);  // 4 passes: ends in (k0, v0)
-        } }
-        if (rc != GS_OK) return rc;
-        { StageScope sc_("rank_list", s);
-        rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist),
-                              (uint32_t*)(g + L.chunk_pairs), a->P, a->debug, s); }
-        if (rc != GS_OK) return rc;
+            if (rc != GS_OK) return rc;
+        } else {  // the LSD radix sort (gs_tuning "depth_sort" = 0): 4 passes, ends in (k0, v0)
+            { StageScope sc_("pair_scan", s);
+            rc = launch_first_pair((const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
+                                   a->P, a->debug, s); }
+            if (rc != GS_OK) return rc;
+            { StageScope sc_("depth_sort", s);
+            rc = launch_sort_pairs(k0, v0, k1, v1, (uint32_t*)(g + L.hist), a->P, 32, true, a->debug, s); }
+            if (rc != GS_OK) return rc;
+            { StageScope sc_("rank_list", s);
+            rc = launch_rank_list(v0, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles), (uint4*)(g + L.ranklist),
+                                  (uint32_t*)(g + L.chunk_pairs), a->P, a->debug, s); }
+            if (rc != GS_OK) return rc;
+        }
     }
     if (count_host_pinned && (!poll || a->P == 0)) {
         hipError_t e = hipMemcpyAsync(count_host_pinned, count, 8, hipMemcpyDeviceToHost, s);
@@ -370,7 +377,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr, nullptr, nullptr,
-                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D}, a->debug, s); }
+                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1}, a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
@@ -617,6 +624,7 @@ int gs_tuning(const char* name, int value) {
     if (!name) return GS_E_BAD_ARG;
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
     if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix
     return GS_E_BAD_ARG;
 }

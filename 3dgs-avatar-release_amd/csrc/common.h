@@ -176,7 +176,7 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
 
 // Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
 int gs_tune_get(int key);
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_COUNT = 8 };
 
 // Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
 // with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
@@ -208,8 +208,12 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                       uint32_t* wave_kmax, ZeroJob zero, hipStream_t s);
 // bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
 struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range; int nb, blocks; };
+// pair numbering done by the sort's first launch (see first_pair_kernel, which the radix path uses) and the rank list
+// written by its last ones (see rank_list_kernel, likewise)
+struct PairNumbering { const uint32_t *tiles, *wave_tiles; float* rec; unsigned long long *count, *host_count; uint32_t* chunk_pairs; int nchunks; };
+struct RankOut { const float* rec; const uint32_t* tiles; uint32_t* sorted_idx; uint4* ranklist; uint32_t* chunk_pairs; };
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
-                      DepthSortState st, uint32_t* sorted_idx, int debug, hipStream_t s);
+                      DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
@@ -274,7 +278,14 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
 
 // `fill`: 16-byte words the kernel's other workgroups set to all-ones while the first one orders the tiles (the
 // backward's ROW_UNWRITTEN marks: a fill launch less, and it overlaps the single-workgroup ordering)
-struct FillJob { uint4* ptr; size_t quads; };
+struct FillJob { uint4* ptr; size_t quads; int stream = 0; };
+
+// 16-byte store that does not stay in the L2 as a dirty line (streamed output nothing re-reads soon)
+typedef uint32_t gs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(uint4* p, uint4 v) {
+    gs_u32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<gs_u32x4*>(p));
+}
 // mode 0: work = ranges[t].y - ranges[t].x; mode 1: work = keys[4 t .. 4 t + 3] summed; mode 2: work = keys[t] = the
 // tile's pair count, and the tile ranges are written first from (loc, grp): see tile_order_kernel
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order,

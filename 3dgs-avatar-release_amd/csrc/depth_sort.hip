@@ -47,14 +47,64 @@ __device__ __forceinline__ void ds_key_range(const uint32_t* __restrict__ wave_k
     *span = hi >= lo ? (unsigned long long)(hi - lo) + 1ull : 1ull;  // (no keyed Gaussian at all: everything goes to bucket nb)
 }
 
+// The same launch numbers the pairs (binning.hip, "Pair numbering": first_pair = exclusive prefix sum of tiles_touched in
+// INDEX order, from the per-wave sums the preprocess kernel left; a workgroup's 2048 Gaussians are 32 of those waves) and
+// delivers the frame's pair count, and clears the per-chunk pair sums the bucket kernels add to.
 __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ wave_kmin,
                                                               const uint32_t* __restrict__ wave_kmax, int nwaves, int P,
                                                               int nb, uint32_t* __restrict__ cnt,
-                                                              uint32_t* __restrict__ krange) {
+                                                              uint32_t* __restrict__ krange, const PairNumbering pn) {
     extern __shared__ uint32_t s_hist[];  // nb + 1 counters + 8 words
     uint32_t* s_red = s_hist + nb + 1;
     const int tid = threadIdx.x;
+    {
+        __shared__ unsigned long long s_before[DS_THREADS / 64];
+        __shared__ uint32_t s_wave[DS_ITEMS / 64 + 1];  // exclusive prefix of this workgroup's wave sums, + their total
+        const int lane = tid & 63, wid = tid >> 6;
+        constexpr int WPB = DS_ITEMS / 64;  // preprocess waves per workgroup of this launch
+        const int w0 = WPB * (int)blockIdx.x;
+        for (int c = blockIdx.x * DS_THREADS + tid; c < pn.nchunks; c += gridDim.x * DS_THREADS) pn.chunk_pairs[c] = 0u;
+        unsigned long long before = 0;  // 64-bit: overflow of the 32-bit index space stays detectable in the count
+        for (int w = tid; w < w0; w += DS_THREADS) before += pn.wave_tiles[w];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+        if (lane == 0) s_before[wid] = before;
+        if (wid == 0) {
+            static_assert(WPB <= 64, "one wave scans the workgroup's wave sums");
+            const uint32_t v = (lane < WPB && w0 + lane < nwaves) ? pn.wave_tiles[w0 + lane] : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane < WPB) s_wave[lane] = x - v;
+            if (lane == 63) s_wave[WPB] = x;
+        }
+        __syncthreads();
+        const unsigned long long block_base = (s_before[0] + s_before[1]) + (s_before[2] + s_before[3]);
+        static_assert(DS_THREADS == 256, "four partial sums");
+#pragma unroll
+        for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
+            const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
+            const uint32_t v = i < P ? pn.tiles[i] : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (i < P) pn.rec[(size_t)i * REC_F + 9] = __uint_as_float((uint32_t)block_base + s_wave[u * (DS_THREADS / 64) + wid] + x - v);
+        }
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+            const unsigned long long total = block_base + s_wave[WPB];
+            pn.count[0] = total;
+            // ... and straight into the caller's pinned host word, which the host is polling: the pair count
+            // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
+            if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     uint32_t k[DS_ITEMS / DS_THREADS];
 #pragma unroll
     for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
@@ -199,6 +249,37 @@ __device__ __forceinline__ void ds_bitonic(const long long n, LOAD load, STORE s
     }
 }
 
+// What binning needs of the Gaussian at every depth rank, written by the bucket kernels as they emit the ranking:
+// (index, rect min x | y << 16, rect size w | h << 16, tiles touched) -- 16 bytes streamed by the binning workgroups
+// instead of a 48-byte record gathered per rank -- and the tiles touched per chunk of 256 consecutive ranks (the binning
+// workgroups cut the ranking into segments of equal WORK with it).  One call per wave and trip: lane l holds rank
+// r0 + l (r0 wave-uniform), which spans at most two chunks; `acc` keeps the running sum of the chunk the wave is in
+// and is added to chunk_pairs (cleared by ds_count_kernel) when the wave moves on: integer adds, order-independent.
+struct ChunkAcc { uint32_t cur = 0xFFFFFFFFu, sum = 0u; };
+__device__ __forceinline__ void chunk_flush(const RankOut& ro, ChunkAcc& acc) {
+    if (acc.cur != 0xFFFFFFFFu && acc.sum != 0u && (threadIdx.x & 63) == 0) atomicAdd(&ro.chunk_pairs[acc.cur], acc.sum);
+}
+__device__ __forceinline__ void rank_emit(const RankOut& ro, uint32_t r, bool valid, uint32_t id, bool keyed, ChunkAcc& acc) {
+    uint32_t tt = 0;
+    if (valid) {
+        const float4 c = reinterpret_cast<const float4*>(ro.rec)[(size_t)id * 3 + 2];
+        tt = ro.tiles[id];
+        ro.sorted_idx[r] = id;
+        ro.ranklist[r] = make_uint4(id, __float_as_uint(c.z), __float_as_uint(c.w), tt);
+    }
+    if (!keyed) return;  // the Gaussians that touch no tile: nothing to add
+    const uint32_t cA = (uint32_t)__builtin_amdgcn_readfirstlane((int)r) >> 8;  // (lane 0 holds the trip's first rank)
+    uint32_t sA = (valid && (r >> 8) == cA) ? tt : 0u, sB = (valid && (r >> 8) != cA) ? tt : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sA += __shfl_xor(sA, d, 64);
+        sB += __shfl_xor(sB, d, 64);
+    }
+    if (acc.cur != cA) { chunk_flush(ro, acc); acc.cur = cA; acc.sum = 0u; }
+    acc.sum += sA;
+    if (sB != 0u) { chunk_flush(ro, acc); acc.cur = cA + 1u; acc.sum = sB; }
+}
+
 // One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~128
 // per bucket): the network runs in LDS without workgroup barriers -- a wave's LDS operations execute in order.
 #define DS_WAVE_CAP 1024
@@ -206,10 +287,11 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
                                                                  const uint32_t* __restrict__ tot,
                                                                  const uint32_t* __restrict__ loc,
                                                                  const uint32_t* __restrict__ grp, int nb,
-                                                                 uint32_t* __restrict__ sorted_idx) {
+                                                                 const RankOut ro) {
     __shared__ unsigned long long s[DS_WAVE_CAP];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;  // bucket; bucket nb holds the Gaussians that touch no tile
+    // bucket; bucket nb holds the Gaussians that touch no tile and is shared by the workgroups nb, nb + 1, ...
+    const int b = min((int)blockIdx.x, nb);
     const int n = (int)tot[b];
     if (n == 0 || (n > DS_WAVE_CAP && b != nb)) return;  // (larger buckets: ds_bucket_sort_kernel)
     uint32_t part = 0;
@@ -218,9 +300,13 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     const uint32_t start = part + loc[b];
     const unsigned long long* seg = tmp + start;
+    ChunkAcc acc;
     if (b == nb) {
         // no order needed among the Gaussians that touch no tile (every later stage skips them)
-        for (int i = lane; i < n; i += 64) sorted_idx[start + i] = (uint32_t)seg[i];
+        for (int i0 = ((int)blockIdx.x - nb) * 64; i0 < n; i0 += ((int)gridDim.x - nb) * 64) {
+            const int i = i0 + lane;
+            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)seg[i] : 0u, false, acc);
+        }
         return;
     }
     // between two steps: nothing may be kept in registers or moved across (the LDS itself keeps a wave's accesses in order)
@@ -254,7 +340,11 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
             step_done();
         }
     }
-    for (int i = lane; i < n; i += 64) sorted_idx[start + i] = (uint32_t)s[i];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
+    }
+    chunk_flush(ro, acc);
 }
 
 // One workgroup per bucket.  Buckets of [n_lo, n_hi] composites are handled by this launch (the others by the launch of
@@ -264,7 +354,7 @@ __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned lon
                                                                     const uint32_t* __restrict__ tot,
                                                                     const uint32_t* __restrict__ loc,
                                                                     const uint32_t* __restrict__ grp, int nb, int n_lo,
-                                                                    uint32_t* __restrict__ sorted_idx) {
+                                                                    const RankOut ro) {
     __shared__ unsigned long long s[CAP];
     __shared__ uint32_t s_grp[4];
     const int tid = threadIdx.x;
@@ -283,17 +373,17 @@ __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned lon
     }
     const uint32_t start = s_grp[0] + s_grp[1] + s_grp[2] + s_grp[3] + loc[b];
     unsigned long long* seg = tmp + start;
-    if (b == nb) {
-        // no order needed among the Gaussians that touch no tile (every later stage skips them)
-        for (int i = tid; i < n; i += DS_THREADS) sorted_idx[start + i] = (uint32_t)seg[i];
-        return;
-    }
+    ChunkAcc acc;
     if (n <= CAP) {
         for (int i = tid; i < n; i += DS_THREADS) s[i] = seg[i];
         __syncthreads();
         ds_bitonic(n, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
                    [&]() { __syncthreads(); });
-        for (int i = tid; i < n; i += DS_THREADS) sorted_idx[start + i] = (uint32_t)s[i];
+        for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
+            const int i = i0 + tid;
+            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
+        }
+        chunk_flush(ro, acc);
         return;
     }
     // A bucket larger than the LDS takes (most of the scene at one depth): the same network in global memory, by this
@@ -303,16 +393,20 @@ __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned lon
                [&](long long i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
                [&](long long i, unsigned long long v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
                [&]() { __threadfence(); __syncthreads(); });
-    for (int i = tid; i < n; i += DS_THREADS)
-        sorted_idx[start + i] = (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
+        const int i = i0 + tid;
+        rank_emit(ro, start + i, i < n,
+                  i < n ? (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, true, acc);
+    }
+    chunk_flush(ro, acc);
 }
 
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
-                      DepthSortState st, uint32_t* sorted_idx, int debug, hipStream_t s) {
+                      DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s) {
     const int nbp = st.nb + 1;
     const size_t lds_count = (size_t)(nbp + 8) * 4, lds_scatter = (size_t)(nbp + 66) * 4;
     hipLaunchKernelGGL(ds_count_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_count, s, keys, wave_kmin, wave_kmax, nwaves, P,
-                       st.nb, st.cnt, st.range);
+                       st.nb, st.cnt, st.range, pn);
     GS_LAUNCH_CHECK("depth_sort.count", debug, s);
     hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(64), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp, nbp,
                        st.blocks);
@@ -322,10 +416,11 @@ int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uin
     GS_LAUNCH_CHECK("depth_sort.scatter", debug, s);
     // a wave per bucket for the buckets of up to DS_WAVE_CAP composites (all of them unless the depths are very unevenly
     // spread), then the larger ones with 128 KB of LDS per workgroup (its workgroups leave at once when there is none)
-    hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(nbp), dim3(64), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, sorted_idx);
+    const int helpers = P / 1024 < 1 ? 1 : (P / 1024 > 512 ? 512 : P / 1024);  // waves sharing the no-tile bucket
+    hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(st.nb + helpers), dim3(64), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, ro);
     GS_LAUNCH_CHECK("depth_sort.buckets", debug, s);
     hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP_BIG>, dim3(nbp), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp,
-                       st.nb, DS_WAVE_CAP + 1, sorted_idx);
+                       st.nb, DS_WAVE_CAP + 1, ro);
     GS_LAUNCH_CHECK("depth_sort.big_buckets", debug, s);
     return GS_OK;
 }

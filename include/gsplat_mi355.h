@@ -267,7 +267,9 @@ int gs_profile_enable(int on);
 int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
 int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
 
-/* process-wide tuning switch for experiments and A/B measurements (e.g. "xcd_map": 0 / 1); no effect on results */
+/* process-wide tuning switch for experiments and A/B measurements; no effect on results.  "xcd_map" (1: the four
+ * quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's
+ * row-mark fill is written with streaming stores) */
 int gs_tuning(const char* name, int value);
 const char* gs_status_string(int code);
 int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */

@@ -322,12 +322,12 @@ def test_knn_at_the_reference_sizes_every_search_variant(oracle):
         assert np.array_equal(got3.view(np.uint32), want3.astype(np.float32).view(np.uint32)), n
 
 
-@pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths"])
+@pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths", "mostly-culled"])
 def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
     """The depth ranking is a bucket sort over the frame's key range (depth_sort.hip): ~128 keys per bucket when the
     depths are evenly spread.  Uneven spreads must give the same bits through its other paths: a bucket beyond 4096 keys
     (second launch, 128 KB of LDS), beyond 16384 (global-memory network), equal keys (ties in ascending index order), a
-    key range stretched by far outliers.  Checked: the ranking itself ((depth bits, index) ascending over the Gaussians
+    key range stretched by far outliers, most Gaussians culled (the bucket of those that touch no tile).  Checked: the ranking itself ((depth bits, index) ascending over the Gaussians
     that touch a tile) and the tile lists against the oracle, bit for bit."""
     from gsplat_mi355 import debug
     dev = torch.device("cuda:0")
@@ -341,6 +341,8 @@ def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
     elif case == "far-outliers":
         cloud.xyz[:40, 2] = torch.empty(40).uniform_(1e4, 1e6, generator=g)  # the key range spans 18 binades
         cloud.xyz[40:, 2] = cloud.xyz[40:, 2] * 0.05                         # ... and the rest sits in 2 % of it
+    elif case == "mostly-culled":
+        cloud.xyz[torch.arange(n) % 10 < 7, 2] = -5.0  # 70 % behind the camera: the no-tile bucket, shared by many waves
     else:
         cloud.xyz[:, 2] = torch.where(torch.arange(n) % 3 == 0, torch.tensor(0.5), torch.tensor(-0.25))
     bg = (0.0, 0.0, 0.0)
