@@ -322,6 +322,36 @@ def test_knn_at_the_reference_sizes_every_search_variant(oracle):
         assert np.array_equal(got3.view(np.uint32), want3.astype(np.float32).view(np.uint32)), n
 
 
+@pytest.mark.parametrize("W,H", [(1500, 90), (90, 1500), (1100, 1090), (2070, 40)])
+def test_tile_lists_across_tile_block_boundaries_with_screen_filling_gaussians(oracle, tile_rect, W, H):
+    """The tile lists are built per block of 64 x 4 tiles and per segment of the depth ranking (binning.hip): image shapes
+    of many blocks in one direction and one (partial) block in the other, Gaussians whose rectangle is the whole grid
+    next to sub-tile ones -- sorted list, ranges and image against the oracle, bit for bit where integer."""
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n = 900
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=77, scale_mul=1.0)
+    cloud.scales[::9] *= 40.0     # every ninth Gaussian covers (nearly) every tile
+    cloud.scales[1::9] *= 0.05    # ... and its neighbour not even one pixel
+    cloud.opacity[::9] *= 0.05    # (so that the lists behind the big ones still contribute)
+    bg = (0.2, 0.1, 0.4)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, tile_rect=tile_rect)
+    fw = oracle.forward(sc)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    ob = fw["binning"]
+    assert np.array_equal(st["radii"], fw["geom"]["radii"])
+    assert np.array_equal(st["geom"]["tiles_touched"], fw["geom"]["tiles_touched"])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    assert int(fw["geom"]["tiles_touched"].max()) >= 0.9 * gx * gy  # rectangles that are (nearly) the whole grid are among them
+    assert st["D"] == ob["D"]
+    assert np.array_equal(st["binning"]["point_list"], ob["point_list"])
+    assert np.array_equal(st["binning"]["tile_ids"], (ob["keys"] >> np.uint64(32)).astype(np.uint32))
+    nz = ob["ranges"][:, 1] > ob["ranges"][:, 0]
+    assert np.array_equal(st["image"]["ranges"][nz], ob["ranges"][nz])
+    _bulk_close(st["color"], fw["color"], frac=1e-4, name="color %dx%d" % (W, H))
+
+
 @pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths", "mostly-culled"])
 def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
     """The depth ranking is a bucket sort over the frame's key range (depth_sort.hip): ~128 keys per bucket when the
