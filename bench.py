@@ -352,6 +352,11 @@ def main(argv=None):
         # the pool has been created AND recorded on this stream before.
         _lib.profile_reserve(2 * K + 64)
         _lib.profile_enable(True, stage=dominant)
+        # A full collection of the interpreter's cyclic garbage collector walks every object torch has created at import
+        # (60-100 ms, observed as ONE step of the timed loop taking that long): collect now -- BEFORE the settle steps,
+        # nothing may leave the GPU idle between them and the timed loop -- and keep it off until the timing is done.
+        gc.collect()
+        gc.disable()
         t_end = time.perf_counter() + 0.7
         while time.perf_counter() < t_end:
             for i in range(8):
@@ -364,10 +369,6 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        # A full collection of the interpreter's cyclic garbage collector walks every object torch has created at import
-        # (60-100 ms, observed as ONE step of the timed loop taking that long): collect now, keep it off while timing.
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         trace = os.environ.get("GSPLAT_BENCH_TRACE") == "1"  # diagnostics only: a synchronise + a line every 25 steps
         worst = (0.0, -1)
