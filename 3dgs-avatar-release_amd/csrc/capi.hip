@@ -19,6 +19,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_XCD_MAP].store(1);
     g_tune[GS_TUNE_DEPTH_SORT].store(1);
     g_tune[GS_TUNE_NT_STORES].store(1);
+    g_tune[GS_TUNE_BWD_CHUNKS].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -220,6 +221,8 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.qlist = cap > 0 ? (uint32_t*)(b + B.qlist) : nullptr;
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
+    ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+    ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -322,6 +325,8 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // rewritten with identical content (same geometry)
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
+    ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+    ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges),
                                (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
@@ -372,6 +377,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.qlist = (uint32_t*)(b + B.qlist);
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
+        ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+        ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
@@ -624,6 +631,7 @@ int gs_tuning(const char* name, int value) {
     if (!name) return GS_E_BAD_ARG;
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
     if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix
     return GS_E_BAD_ARG;

@@ -117,9 +117,18 @@ static inline int bin_segments(const BinGrid& G, int P) {
     return s < G.nseg_max ? s : G.nseg_max;
 }
 
+// Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
+// entries -- leaves most SIMDs idle while a handful of waves walk their quadrant's list alone, one dependent step after
+// the other.  The forward therefore checkpoints the per-pixel compositing state (T, C) every BWD_CH compacted entries
+// and the backward runs one wave per (quadrant, chunk of BWD_CH entries), each starting from its checkpoint.  Only for
+// images of up to BWD_CHUNK_MAX_TILES tiles: a larger frame fills the chip with one wave per quadrant.
+#define BWD_CH 256
+#define BWD_KMAX 8   // chunks per quadrant; the last one takes whatever lies beyond (BWD_KMAX - 1) BWD_CH entries
+#define BWD_CHUNK_MAX_TILES 2048
+
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, total;
-    int gx, gy;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, total;
+    int gx, gy, bwd_chunks;
 };
 static inline ImgLayout img_layout(int W, int H) {
     ImgLayout L;
@@ -138,6 +147,9 @@ static inline ImgLayout img_layout(int W, int H) {
     L.tile_tot = take(nt * 4);                     // pairs per tile
     L.tile_loc = take(nt * 4);                     // ... and their exclusive prefix inside the tile's group of 64 tiles
     L.grp_sum = take((nt / 64 + 1) * 4);           // pairs per group of 64 tiles
+    L.bwd_chunks = nt <= BWD_CHUNK_MAX_TILES ? BWD_KMAX : 1;
+    // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
+    L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
     L.total = o;
     return L;
 }
@@ -176,7 +188,7 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
 
 // Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
 int gs_tune_get(int key);
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_COUNT = 8 };
 
 // Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
 // with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
@@ -296,6 +308,8 @@ struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
+    float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
+    int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ dL_dpix,
                                                         const float* __restrict__ dL_dopa,
                                                         const float* __restrict__ final_T, const float* __restrict__ bg,
-                                                        float4* __restrict__ qrows, uint32_t* __restrict__ q8) {
+                                                        float4* __restrict__ qrows, uint32_t* __restrict__ q8,
+                                                        const float4* __restrict__ ckpt, const int chunks,
+                                                        const int blocks_per_chunk) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
@@ -112,7 +114,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
     __shared__ float pix[OPA ? 7 : 6][4 * RING_STRIDE];  // (+ the opacity channel's gradient)
     int slot, q;
-    render_block_map((int)blockIdx.x, xmap, &slot, &q);
+    // chunk-major: all first chunks, heaviest tiles first, then all second chunks, ... (chunks = 1: one wave per quadrant)
+    const int chunk = chunks > 1 ? (int)blockIdx.x / blocks_per_chunk : 0;
+    render_block_map((int)blockIdx.x - chunk * blocks_per_chunk, xmap, &slot, &q);
     if (slot >= ntiles) return;
     const int tile = (int)order[slot];  // heaviest tiles first (tile_order_kernel on the forward's counts)
     const int tx = tile % gx, ty = tile / gx;
@@ -122,11 +126,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const int px = QX0 + (lane & 7), py = QY0 + (lane >> 3);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;
-    const int m = (int)qcount[tile * 4 + q];
-    if (m == 0) return;
+    // this wave's entries: [k0, k0 + m) of the quadrant's compacted list (the whole list when chunks = 1)
+    const int m_all = (int)qcount[tile * 4 + q];
+    const int k0 = chunk * BWD_CH;
+    if (k0 >= m_all) return;
+    const int m = (chunk == chunks - 1) ? m_all - k0 : min(m_all - k0, BWD_CH);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n + (uint32_t)k0;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float gtot0;  // Gtot of pixel `lane`
+    float gtot0, T0 = 1.0f;  // Gtot of pixel `lane` (what of it is not composited before entry k0), its transmittance there
     {
         // (g0, g1, g2, Gtot) and (x, y, lim): the pixel at position i of its ring meets compacted entry k at
         // step s = k + i, and the pair counts only while k < (its last contributor) <=> s < lim = ncon + i
@@ -136,11 +143,19 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const size_t pid = (size_t)py * W + px;
             const float g0 = dL_dpix[pid], g1 = dL_dpix[HW + pid], g2 = dL_dpix[2 * HW + pid];
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
-            c1.z = __uint_as_float(ncon_c[pid] + (uint32_t)j);
+            const uint32_t nc = ncon_c[pid];
+            c1.z = __uint_as_float((nc > (uint32_t)k0 ? nc - (uint32_t)k0 : 0u) + (uint32_t)j);
             if (OPA) {
                 const float Tf = final_T[pid];
                 c1.w = dL_dopa[pid];
                 c0.w += ((1.0f - Tf) + Tf * bg[0]) * c1.w;  // the opacity channel's share of Gtot
+            }
+            if (chunk > 0) {
+                // the forward's state before entry k0: T, and the colour composited so far (the opacity channel's is 1 - T)
+                const float4 ck = ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)(chunk - 1)) * 64 + lane];
+                T0 = ck.x;
+                c0.w -= ck.y * g0 + ck.z * g1 + ck.w * g2;
+                if (OPA) c0.w -= (1.0f - ck.x) * c1.w;
             }
         }
         const int slot = ring * RING_STRIDE + j;
@@ -200,7 +215,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
     // (position i of a ring starts at ring lane (16 - i) mod 16; fetch its Gtot from the lane that loaded it)
-    float T = 1.0f, Rem = __shfl(gtot0, ring * RING + ((RING - j) & (RING - 1)), 64);
+    float T = __shfl(T0, ring * RING + ((RING - j) & (RING - 1)), 64);
+    float Rem = __shfl(gtot0, ring * RING + ((RING - j) & (RING - 1)), 64);
 
     // A finished entry's nine RAW sums go to its row in HBM.  What is constant per Gaussian -- opacity,
     // the conic combination of the two first moments, the -1/2 and 1/log2(e) factors -- is applied once
@@ -315,15 +331,17 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
-    const dim3 grid(render_grid_blocks(gx * gy, xmap));
+    const int chunks = ql.ckpt ? ql.chunks : 1;
+    const int bpc = render_grid_blocks(gx * gy, xmap);
+    const dim3 grid((unsigned)bpc * (unsigned)chunks);
     if (dL_dopa)
         hipLaunchKernelGGL(render_bwd_kernel<true>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                            reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, chunks, bpc);
     else
         hipLaunchKernelGGL(render_bwd_kernel<false>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                            reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8);
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, chunks, bpc);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

@@ -26,8 +26,9 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib,
                                                         uint32_t* __restrict__ qlist, uint32_t* __restrict__ ncon_c,
-                                                        uint32_t* __restrict__ qcount) {
-    __shared__ float4 srec[64 * 3];
+                                                        uint32_t* __restrict__ qcount, float4* __restrict__ ckpt,
+                                                        const int chunks) {
+    __shared__ float4 srec[66 * 3];  // 64 staged entries + the two the pipelined loop may read past a batch
     int slot, q;
     render_block_map((int)blockIdx.x, xmap, &slot, &q);
     if (slot >= ntiles) return;
@@ -92,15 +93,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         // the CU's single scalar unit becomes the bottleneck.
         const char* sp = reinterpret_cast<const char*>(srec) + vzero;
         const uint32_t kbase = kcount - (uint32_t)cnt;  // compacted index of this batch's first entry
-        for (int j = 0; j < cnt; j++) {
-            const float4 a = *reinterpret_cast<const float4*>(sp);
-            const float4 b = *reinterpret_cast<const float4*>(sp + 16);
-            const float4 c = *reinterpret_cast<const float4*>(sp + 32);
-            // keep the whole 16 bytes of `c` one ds_read_b128 (4 LDS cycles): only r, g, b are used in the loop, and
-            // the 12-byte ds_read_b96 the compiler would pick takes 8 -- with it the loop needs 14 LDS cycles per entry
-            // and wave, 56 per four SIMDs against 52 cycles of VALU issue: the kernel was LDS-bound
-            asm volatile("" ::"v"(c.w));
-            sp += 48;
+        // One entry against the 64 pixels.  `a`, `b`, `c` = the three staged quads of the entry.
+        auto blend = [&](const float4 a, const float2 b, const float4 c, const uint32_t k1) {
             const float dx = a.x - pxf, dy = a.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2, evaluated exactly as the backward does
             const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
@@ -115,7 +109,53 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
-            last_k = (w > 0.f) ? (kbase + (uint32_t)j + 1u) : last_k;  // (a wave-uniform value: no LDS operand)
+            last_k = (w > 0.f) ? k1 : last_k;  // (a wave-uniform value: no LDS operand)
+        };
+        // The loop is software-pipelined by hand, two entries per trip: the LDS reads of the NEXT entry are issued
+        // before the current one is evaluated.  With eight waves per SIMD the LDS latency hides behind the other waves
+        // anyway; a frame of few, long lists (a trained avatar: 150 tiles of 2000-7000 entries) runs one wave per SIMD
+        // and paid the ~100 cycles of every entry's reads in full.  (Reads one entry past the batch: srec has a 65th.)
+        auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
+        auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
+        auto ld_c = [&](int o) {
+            const float4 c = *reinterpret_cast<const float4*>(sp + o + 32);
+            // keep the whole 16 bytes of `c` one ds_read_b128 (4 LDS cycles): only r, g, b are used in the loop, and
+            // the 12-byte ds_read_b96 the compiler would pick takes 8 -- with it the loop needs 14 LDS cycles per entry
+            // and wave, 56 per four SIMDs against 52 cycles of VALU issue: the kernel was LDS-bound
+            asm volatile("" ::"v"(c.w));
+            return c;
+        };
+        // entries [j0, j1) of the batch
+        auto run = [&](const int j0, const int j1) {
+            float4 a0 = ld_a(0), c0 = ld_c(0);
+            float2 b0 = ld_b(0);
+            int j = j0;
+            for (; j + 1 < j1; j += 2) {
+                const float4 a1 = ld_a(48), c1 = ld_c(48);
+                const float2 b1 = ld_b(48);
+                blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
+                a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
+                sp += 96;
+                blend(a1, b1, c1, kbase + (uint32_t)j + 2u);
+            }
+            if (j < j1) {
+                blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
+                sp += 48;
+            }
+        };
+        // A chunk of the backward starts at every compacted index c BWD_CH, 0 < c < chunks (common.h, BWD_CH): the state
+        // BEFORE that entry is checkpointed.  At most one such index falls into a batch (64 <= BWD_CH): the batch is run
+        // in two parts around it -- nothing is tested per entry.
+        int jc = cnt;
+        if (chunks > 1) {
+            const uint32_t r = (BWD_CH - (kbase & (BWD_CH - 1u))) & (BWD_CH - 1u);
+            if (r < (uint32_t)cnt && kbase + r > 0u && kbase + r < (uint32_t)chunks * BWD_CH) jc = (int)r;
+        }
+        run(0, jc);
+        if (jc < cnt) {
+            ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + ((kbase + (uint32_t)jc) / BWD_CH - 1u)) * 64 + lane] =
+                make_float4(fabsf(T), C0, C1, C2);
+            run(jc, cnt);
         }
         // the last contributor's position in the TILE's list (n_contrib), looked up once per batch
         if (last_k > kbase) last = __float_as_uint(srec[(last_k - 1u - kbase) * 3 + 2].w);
@@ -145,7 +185,8 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s,
                        reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg,
-                       W, H, gx, gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount);
+                       W, H, gx, gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt,
+                       ql.ckpt ? ql.chunks : 1);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }

@@ -61,16 +61,55 @@ class GaussianCloud(object):
                              parts[3].view(n, 1).clone(), parts[4].view(n, m, 3).clone(), sh_degree)
 
 
-def synthetic_cloud(n, sh_degree=3, seed=0, dist2_fn=None, heavy_tail=0.0, device="cpu"):
+# a standing figure of capsules (segment end points, radius) inside the [-1, 1]^3 box, y up: torso, head, arms, legs
+_BODY = [((0.0, -0.10, 0.0), (0.0, 0.50, 0.0), 0.17), ((0.0, 0.64, 0.0), (0.0, 0.74, 0.0), 0.11),
+         ((-0.22, 0.45, 0.0), (-0.55, 0.00, 0.05), 0.05), ((0.22, 0.45, 0.0), (0.55, 0.00, 0.05), 0.05),
+         ((-0.10, -0.15, 0.0), (-0.16, -0.92, 0.0), 0.08), ((0.10, -0.15, 0.0), (0.16, -0.92, 0.0), 0.08)]
+
+
+def _body_points(n, g):
+    """Points on the surface of the capsule figure (+ 2 mm of noise): the shape of a TRAINED avatar cloud -- the
+    Gaussians on a thin shell that covers a fraction of the image -- where synthetic_cloud's default is the reference's
+    initial state (uniform in the box)."""
+    p0 = torch.tensor([c[0] for c in _BODY])
+    p1 = torch.tensor([c[1] for c in _BODY])
+    r = torch.tensor([c[2] for c in _BODY])
+    length = (p1 - p0).norm(dim=1)
+    area = 2 * math.pi * r * (length + 2 * r)  # cylinder + the two half-sphere caps
+    which = torch.multinomial(area / area.sum(), n, replacement=True, generator=g)
+    u = torch.rand(n, generator=g) * (length + 2 * r)[which]  # position along the capsule, caps unrolled
+    axis = ((p1 - p0) / length[:, None])[which]
+    helper = torch.where(axis[:, 1:2].abs() < 0.9, torch.tensor([[0.0, 1.0, 0.0]]), torch.tensor([[1.0, 0.0, 0.0]]))
+    e1 = torch.linalg.cross(axis, helper.expand_as(axis))
+    e1 = e1 / e1.norm(dim=1, keepdim=True)
+    e2 = torch.linalg.cross(axis, e1)
+    phi = torch.rand(n, generator=g) * 2 * math.pi
+    ring = torch.cos(phi)[:, None] * e1 + torch.sin(phi)[:, None] * e2
+    rr, ll = r[which], length[which]
+    t = (u - rr).clamp(min=0.0) .clamp(max=1e9)
+    t = torch.minimum(t, ll)                      # foot point on the segment
+    over = torch.where(u < rr, u - rr, torch.where(u > rr + ll, u - rr - ll, torch.zeros_like(u)))  # signed run onto a cap
+    theta = over / rr                             # angle from the rim towards the pole, within +-1 rad of the rim
+    normal = torch.cos(theta)[:, None] * ring + torch.sin(theta)[:, None] * axis
+    pts = p0[which] + t[:, None] * axis + rr[:, None] * normal
+    return pts + 0.002 * torch.randn(n, 3, generator=g)
+
+
+def synthetic_cloud(n, sh_degree=3, seed=0, dist2_fn=None, heavy_tail=0.0, device="cpu", layout="box"):
     """SURVEY.md 8d scene.  `dist2_fn(points[N,3]) -> [N]` is the distCUDA2 implementation to use
     (the HIP one on a GPU; tests on CPU pass the oracle's).  `heavy_tail` > 0 multiplies the scales
-    of that fraction of the Gaussians by 4 (BASELINE config 5: tile-overflow / sort stress)."""
+    of that fraction of the Gaussians by 4 (BASELINE config 5: tile-overflow / sort stress).  `layout`: "box" = the
+    reference's initial state (uniform in the box, opacity around 0.1); "body" = the shape of a trained avatar (a thin
+    shell on a capsule figure, mostly opaque)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    xyz = torch.rand(n, 3, generator=g) * 2 - 1
+    if layout == "body":
+        xyz = _body_points(n, g)
+    else:
+        xyz = torch.rand(n, 3, generator=g) * 2 - 1
     aniso = torch.exp(torch.randn(n, 3, generator=g) * 0.3)
     rot = torch.randn(n, 4, generator=g)
     rot = rot / rot.norm(dim=1, keepdim=True)
-    opacity = torch.sigmoid(inverse_sigmoid(0.1) + torch.randn(n, 1, generator=g))
+    opacity = torch.sigmoid((2.0 if layout == "body" else inverse_sigmoid(0.1)) + torch.randn(n, 1, generator=g) * (1.5 if layout == "body" else 1.0))
     m = (sh_degree + 1) ** 2
     shs = torch.randn(n, m, 3, generator=g) * 0.05
     shs[:, 0, :] = rgb_to_sh(torch.rand(n, 3, generator=g))

@@ -55,7 +55,11 @@ WORKLOADS = {
     "config4": (200000, 512, 512, 3, 0.0, True),
     "config5": (500000, 2048, 2048, 3, 0.05, True),
     "tiny": (20000, 256, 256, 3, 0.0, True),
+    # not a BASELINE configuration: the shape of a TRAINED avatar (200k Gaussians on a thin shell covering a fraction of
+    # the 512 x 512 image, mostly opaque) next to config 4's initial-state cloud -- few, long tile lists
+    "avatar": (200000, 512, 512, 3, 0.0, True),
 }
+WORKLOAD_LAYOUT = {"avatar": "body"}
 
 # kernel (rocprofv3 name) -> bench stage it belongs to
 KERNEL_STAGE = {"preprocess_kernel": "preprocess", "render_fwd_kernel": "render_fwd", "render_bwd_kernel": "render_bwd",
@@ -244,7 +248,8 @@ def main(argv=None):
     N, W, H, deg, tail, do_bwd = WORKLOADS[args.workload]
 
     # ---- Gaussian state: built on rank 0, one RCCL broadcast
-    cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev) if rank == 0 else None
+    cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev,
+                            layout=WORKLOAD_LAYOUT.get(args.workload, "box")) if rank == 0 else None
     t_bcast = 0.0
     if world > 1:
         torch.cuda.synchronize()

@@ -8,10 +8,10 @@ from gsplat_mi355.camera import Camera, focal2fov, orbit_camera
 from gsplat_mi355.scenes import synthetic_cloud
 
 
-def cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=0, dist2_fn=None, heavy_tail=0.0, scale_mul=1.0):
+def cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=0, dist2_fn=None, heavy_tail=0.0, scale_mul=1.0, layout="box"):
     from oracle import gs_oracle
     fn = dist2_fn or (lambda p: torch.from_numpy(gs_oracle.dist2(p.cpu().numpy())))
-    cloud = synthetic_cloud(n, sh_degree=sh_degree, seed=seed, dist2_fn=fn, heavy_tail=heavy_tail)
+    cloud = synthetic_cloud(n, sh_degree=sh_degree, seed=seed, dist2_fn=fn, heavy_tail=heavy_tail, layout=layout)
     if scale_mul != 1.0:
         cloud.scales = cloud.scales * scale_mul
     cam = orbit_camera(frame, W, H)

@@ -322,6 +322,61 @@ def test_knn_at_the_reference_sizes_every_search_variant(oracle):
         assert np.array_equal(got3.view(np.uint32), want3.astype(np.float32).view(np.uint32)), n
 
 
+@pytest.mark.parametrize("with_opacity", [False, True])
+def test_long_lists_on_a_small_image_backward_in_chunks(oracle, with_opacity):
+    """A trained-avatar shaped frame: 30000 Gaussians on a thin shell covering a fraction of a 160 x 160 image, i.e. few
+    quadrants with lists of thousands of entries.  On images of up to 2048 tiles the forward checkpoints the compositing
+    state every 256 compacted entries and the backward runs one wave per (quadrant, chunk) from those checkpoints
+    (common.h, BWD_CH): gradients against the oracle, and against the one-wave-per-quadrant walk of the same frame
+    (gs_tuning "bwd_chunks" = 0), with and without the fused opacity channel."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsplat_mi355 import _lib, debug
+    dev = torch.device("cuda:0")
+    n, W, H = 30000, 160, 160
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=5, layout="body")
+    cloud.opacity = cloud.opacity * 0.25  # translucent: the walks go deep into the lists
+    bg = (0.1, 0.2, 0.3)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg)
+    fw = oracle.forward(sc)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3))
+    gopa = torch.randn(1, H, W, generator=torch.Generator().manual_seed(4))
+    want = oracle.backward(sc, fw, gimg.numpy())
+
+    def run(chunks):
+        _lib.tuning("bwd_chunks", chunks)
+        try:
+            kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+            means3D = cloud.xyz.to(dev).requires_grad_(True)
+            means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+            opac = cloud.opacity.to(dev).requires_grad_(True)
+            rast = GaussianRasterizer(_settings(cam, cloud, bg, dev))
+            if with_opacity:
+                color, radii, opa = rast(means3D=means3D, means2D=means2D, opacities=opac, with_opacity=True, **kw)
+                ((color * gimg.to(dev)).sum() + (opa * gopa.to(dev)).sum()).backward()
+            else:
+                color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+                (color * gimg.to(dev)).sum().backward()
+            out = dict(color=color.detach(), means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad)
+            out.update({k: v.grad for k, v in kw.items()})
+            return {k: v.cpu().numpy() for k, v in out.items()}
+        finally:
+            _lib.tuning("bwd_chunks", 1)
+
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             **_inputs(cloud, cam, "sh", "scale_rot", dev))
+    assert int(st["image"]["qcount"].max()) > 3 * 256  # quadrants of more than three chunks are among them
+    a, b = run(1), run(0)
+    assert np.array_equal(a["color"], b["color"])  # (the forward is the same kernel: the checkpoints are a side output)
+    for k in a:
+        scale = np.abs(b[k]).max()
+        assert scale > 0 and np.abs(a[k] - b[k]).max() <= 2e-6 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
+    if not with_opacity:
+        names = dict(shs="sh", scales="scales", rotations="rotations", means3D="means3D", means2D="means2D", opacities="opacities")
+        _bulk_close(a["color"], fw["color"], frac=1e-3, name="color")
+        for k, ok in names.items():
+            _bulk_close(a[k], want[ok].reshape(a[k].shape), tol=5e-5, frac=2e-3, name="chunked " + k)
+
+
 @pytest.mark.parametrize("W,H", [(1500, 90), (90, 1500), (1100, 1090), (2070, 40)])
 def test_tile_lists_across_tile_block_boundaries_with_screen_filling_gaussians(oracle, tile_rect, W, H):
     """The tile lists are built per block of 64 x 4 tiles and per segment of the depth ranking (binning.hip): image shapes

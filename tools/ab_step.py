@@ -42,7 +42,7 @@ else:
 
 N, W, H, deg, tail, do_bwd = bench.WORKLOADS[args.workload]
 dev = torch.device("cuda:0")
-cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev)
+cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev, layout=bench.WORKLOAD_LAYOUT.get(args.workload, "box"))
 for f in GaussianCloud.FIELDS:
     getattr(cloud, f).requires_grad_(do_bwd)
 cams = [orbit_camera(f, W, H, device=dev) for f in range(args.steps)]
