@@ -223,6 +223,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
+    ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -327,6 +328,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
+    ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges),
                                (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
@@ -379,6 +381,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
         ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
         ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
+    ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups

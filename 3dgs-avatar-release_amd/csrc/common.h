@@ -119,15 +119,16 @@ static inline int bin_segments(const BinGrid& G, int P) {
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
 // entries -- leaves most SIMDs idle while a handful of waves walk their quadrant's list alone, one dependent step after
-// the other.  The forward therefore checkpoints the per-pixel compositing state (T, C) every BWD_CH compacted entries
-// and the backward runs one wave per (quadrant, chunk of BWD_CH entries), each starting from its checkpoint.  Only for
-// images of up to BWD_CHUNK_MAX_TILES tiles: a larger frame fills the chip with one wave per quadrant.
+// the other.  The forward therefore checkpoints the per-pixel compositing state (T, C) at the first batch boundary at
+// least BWD_CH compacted entries after the previous checkpoint, notes the compacted index it stands at (ck_start), and
+// the backward runs one wave per (quadrant, chunk), each starting from its checkpoint.  Only for images of up to
+// BWD_CHUNK_MAX_TILES tiles: a larger frame fills the chip with one wave per quadrant.
 #define BWD_CH 256
-#define BWD_KMAX 8   // chunks per quadrant; the last one takes whatever lies beyond (BWD_KMAX - 1) BWD_CH entries
+#define BWD_KMAX 8   // chunks per quadrant; the last one takes whatever lies beyond the last checkpoint
 #define BWD_CHUNK_MAX_TILES 2048
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, ck_start, total;
     int gx, gy, bwd_chunks;
 };
 static inline ImgLayout img_layout(int W, int H) {
@@ -150,6 +151,7 @@ static inline ImgLayout img_layout(int W, int H) {
     L.bwd_chunks = nt <= BWD_CHUNK_MAX_TILES ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
+    L.ck_start = take(nt * 4 * (size_t)L.bwd_chunks * 4);  // [quadrant][chunk]: first compacted entry of the chunk, ~0 = none
     L.total = o;
     return L;
 }
@@ -309,6 +311,7 @@ struct QuadLists {
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
     float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
+    uint32_t* ck_start = nullptr;  // [quadrant][chunks]: compacted index every chunk starts at
     int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ dL_dopa,
                                                         const float* __restrict__ final_T, const float* __restrict__ bg,
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8,
-                                                        const float4* __restrict__ ckpt, const int chunks,
+                                                        const float4* __restrict__ ckpt,
+                                                        const uint32_t* __restrict__ ck_start, const int chunks,
                                                         const int blocks_per_chunk) {
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
@@ -128,9 +129,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const int n = (int)(range.y - range.x);
     // this wave's entries: [k0, k0 + m) of the quadrant's compacted list (the whole list when chunks = 1)
     const int m_all = (int)qcount[tile * 4 + q];
-    const int k0 = chunk * BWD_CH;
-    if (k0 >= m_all) return;
-    const int m = (chunk == chunks - 1) ? m_all - k0 : min(m_all - k0, BWD_CH);
+    const uint32_t ks = chunk > 0 ? ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + chunk] : 0u;
+    if (ks >= (uint32_t)m_all) return;  // (also: chunk never begun, ~0)
+    const int k0 = (int)ks;
+    const uint32_t ke = chunk + 1 < chunks ? ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + chunk + 1] : 0xFFFFFFFFu;
+    const int m = (int)min(ke, (uint32_t)m_all) - k0;
     const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n + (uint32_t)k0;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float gtot0, T0 = 1.0f;  // Gtot of pixel `lane` (what of it is not composited before entry k0), its transmittance there
@@ -337,11 +340,11 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
     if (dL_dopa)
         hipLaunchKernelGGL(render_bwd_kernel<true>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                            reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, chunks, bpc);
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, ql.ck_start, chunks, bpc);
     else
         hipLaunchKernelGGL(render_bwd_kernel<false>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
                            reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, chunks, bpc);
+                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, ql.ck_start, chunks, bpc);
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
                                                         uint32_t* __restrict__ n_contrib,
                                                         uint32_t* __restrict__ qlist, uint32_t* __restrict__ ncon_c,
                                                         uint32_t* __restrict__ qcount, float4* __restrict__ ckpt,
-                                                        const int chunks) {
+                                                        uint32_t* __restrict__ ck_start, const int chunks) {
     __shared__ float4 srec[66 * 3];  // 64 staged entries + the two the pipelined loop may read past a batch
     int slot, q;
     render_block_map((int)blockIdx.x, xmap, &slot, &q);
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     float T = inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;  // wave-uniform: compacted entries staged so far
+    int nck = 0;                   // checkpoints written so far (chunks of the backward begun, less one)
+    uint32_t next_ck = BWD_CH;     // ... the next one is due at the first batch that starts at or beyond this entry
     bool live = __ballot(T > 0.f) != 0ull;  // wave-uniform
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
@@ -93,6 +95,14 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         // the CU's single scalar unit becomes the bottleneck.
         const char* sp = reinterpret_cast<const char*>(srec) + vzero;
         const uint32_t kbase = kcount - (uint32_t)cnt;  // compacted index of this batch's first entry
+        // a chunk of the backward starts here when the previous one has its BWD_CH entries (common.h, BWD_CH): the state
+        // before this batch is checkpointed
+        if (nck + 1 < chunks && kbase >= next_ck) {
+            ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)nck) * 64 + lane] = make_float4(fabsf(T), C0, C1, C2);
+            nck++;
+            if (lane == 0) ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + nck] = kbase;
+            next_ck = kbase + BWD_CH;
+        }
         // One entry against the 64 pixels.  `a`, `b`, `c` = the three staged quads of the entry.
         auto blend = [&](const float4 a, const float2 b, const float4 c, const uint32_t k1) {
             const float dx = a.x - pxf, dy = a.y - pyf;
@@ -125,38 +135,18 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             asm volatile("" ::"v"(c.w));
             return c;
         };
-        // entries [j0, j1) of the batch
-        auto run = [&](const int j0, const int j1) {
-            float4 a0 = ld_a(0), c0 = ld_c(0);
-            float2 b0 = ld_b(0);
-            int j = j0;
-            for (; j + 1 < j1; j += 2) {
-                const float4 a1 = ld_a(48), c1 = ld_c(48);
-                const float2 b1 = ld_b(48);
-                blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
-                a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
-                sp += 96;
-                blend(a1, b1, c1, kbase + (uint32_t)j + 2u);
-            }
-            if (j < j1) {
-                blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
-                sp += 48;
-            }
-        };
-        // A chunk of the backward starts at every compacted index c BWD_CH, 0 < c < chunks (common.h, BWD_CH): the state
-        // BEFORE that entry is checkpointed.  At most one such index falls into a batch (64 <= BWD_CH): the batch is run
-        // in two parts around it -- nothing is tested per entry.
-        int jc = cnt;
-        if (chunks > 1) {
-            const uint32_t r = (BWD_CH - (kbase & (BWD_CH - 1u))) & (BWD_CH - 1u);
-            if (r < (uint32_t)cnt && kbase + r > 0u && kbase + r < (uint32_t)chunks * BWD_CH) jc = (int)r;
+        float4 a0 = ld_a(0), c0 = ld_c(0);
+        float2 b0 = ld_b(0);
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) {
+            const float4 a1 = ld_a(48), c1 = ld_c(48);
+            const float2 b1 = ld_b(48);
+            blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
+            a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
+            sp += 96;
+            blend(a1, b1, c1, kbase + (uint32_t)j + 2u);
         }
-        run(0, jc);
-        if (jc < cnt) {
-            ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + ((kbase + (uint32_t)jc) / BWD_CH - 1u)) * 64 + lane] =
-                make_float4(fabsf(T), C0, C1, C2);
-            run(jc, cnt);
-        }
+        if (j < cnt) blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
         // the last contributor's position in the TILE's list (n_contrib), looked up once per batch
         if (last_k > kbase) last = __float_as_uint(srec[(last_k - 1u - kbase) * 3 + 2].w);
         live = __ballot(T > 0.f) != 0ull;  // every pixel of the quadrant frozen: stop
@@ -164,6 +154,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     {
         const uint32_t nm = wave_max_u32(last_k);
         if (lane == 0) qcount[tile * 4 + q] = nm;  // the backward's loop bound / work estimate for this quadrant
+        // chunks of the backward that never began
+        if (chunks > 1 && lane > nck && lane < chunks) ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + lane] = 0xFFFFFFFFu;
     }
     if (inside) {
         const size_t HW = (size_t)H * W;
@@ -186,7 +178,7 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s,
                        reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg,
                        W, H, gx, gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt,
-                       ql.ckpt ? ql.chunks : 1);
+                       ql.ck_start, ql.ckpt ? ql.chunks : 1);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }
