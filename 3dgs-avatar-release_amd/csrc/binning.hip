@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
                                                           uint32_t* __restrict__ order, uint2* __restrict__ ranges_out,
                                                           const uint32_t* __restrict__ loc,
                                                           const uint32_t* __restrict__ grp, const PairCount pc,
-                                                          const FillJob fill) {
+                                                          const FillJob fill, const int mark_wide) {
     if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
@@ -564,30 +564,41 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     for (int w = 0; w < wid; w++) woff += wsum[w];
     hist[tid] = woff + x - v;
     __syncthreads();
+    // Small images (mark_wide, forward only): a tile whose list is long against the frame's total keeps a quadrant wave
+    // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
+    // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
+    uint32_t wide_from = 0xFFFFFFFFu;
+    if (mark_wide && mode == 2) {
+        const unsigned long long D = *pc.dev;
+        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
+    }
     if (HELD) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (i * 1024 >= ntiles) break;
             const int t = i * 1024 + tid;
-            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t;
+            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t | (held[i] > wide_from ? 0x80000000u : 0u);
         }
     } else {
-        for (int t = tid; t < ntiles; t += 1024)
-            order[atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u)] = (uint32_t)t;
+        for (int t = tid; t < ntiles; t += 1024) {
+            const uint32_t wk = tile_work(ranges, keys, mode, t);
+            order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (wk > wide_from ? 0x80000000u : 0u);
+        }
     }
 }
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, uint32_t* ranges_out,
                       const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, int debug, hipStream_t s) {
+    const int mark_wide = (mode == 2 && forward_small_image(ntiles)) ? 1 : 0;
     // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
     const size_t pieces = (fill.quads + 1023) / 1024;
     const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, mark_wide);
     else
         hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, mark_wide);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }

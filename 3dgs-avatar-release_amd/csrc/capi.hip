@@ -20,6 +20,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_DEPTH_SORT].store(1);
     g_tune[GS_TUNE_NT_STORES].store(1);
     g_tune[GS_TUNE_BWD_CHUNKS].store(1);
+    g_tune[GS_TUNE_FWD4].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -576,6 +577,7 @@ int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
         case 2: *out = m + I.final_T; break;
         case 3: *out = m + I.tile_nmax; break;
         case 4: *out = m + I.ncon_c; break;
+        case 5: *out = m + I.order; break;
         default: return GS_E_BAD_ARG;
     }
     return GS_OK;
@@ -634,6 +636,7 @@ int gs_tuning(const char* name, int value) {
     if (!name) return GS_E_BAD_ARG;
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
     if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix

@@ -126,6 +126,9 @@ static inline int bin_segments(const BinGrid& G, int P) {
 #define BWD_CH 256
 #define BWD_KMAX 8   // chunks per quadrant; the last one takes whatever lies beyond the last checkpoint
 #define BWD_CHUNK_MAX_TILES 2048
+#define FWD4_MAX_TILES 2048   // the forward runs four waves per quadrant up to this many tiles (render_fwd.hip)
+#define FWD4_MIN_LIST 512u    // ... all four on the tiles whose list is longer than this and than (frame's pairs) / FWD4_TOTAL_DIV
+#define FWD4_TOTAL_DIV 320ull
 
 struct ImgLayout {
     size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, ck_start, total;
@@ -190,7 +193,7 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
 
 // Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
 int gs_tune_get(int key);
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_COUNT = 8 };
 
 // Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
 // with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
@@ -206,6 +209,8 @@ __device__ __forceinline__ void render_block_map(int b, int xmap, int* slot, int
         *q = b & 3;
     }
 }
+// the forward runs four waves per quadrant, and tile_order_kernel marks the tiles that use them all (render_fwd.hip)
+static inline bool forward_small_image(int ntiles) { return ntiles <= FWD4_MAX_TILES && gs_tune_get(GS_TUNE_FWD4) != 0; }
 static inline int render_grid_blocks(int ntiles, int xmap) { return xmap ? ((ntiles + 7) / 8) * 32 : ntiles * 4; }
 
 struct StageScope {

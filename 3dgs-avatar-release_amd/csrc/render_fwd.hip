@@ -17,29 +17,52 @@
 #include "common.h"
 #include "blend.h"
 
-__global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict__ rec,
-                                                        const uint32_t* __restrict__ point_list,
-                                                        const uint2* __restrict__ ranges,
-                                                        const uint32_t* __restrict__ order,
-                                                        const float* __restrict__ bg, int W, int H, int gx,
-                                                        int ntiles, int xmap,
-                                                        float* __restrict__ out_color, float* __restrict__ final_T,
-                                                        uint32_t* __restrict__ n_contrib,
-                                                        uint32_t* __restrict__ qlist, uint32_t* __restrict__ ncon_c,
-                                                        uint32_t* __restrict__ qcount, float4* __restrict__ ckpt,
-                                                        uint32_t* __restrict__ ck_start, const int chunks) {
-    __shared__ float4 srec[66 * 3];  // 64 staged entries + the two the pipelined loop may read past a batch
-    int slot, q;
-    render_block_map((int)blockIdx.x, xmap, &slot, &q);
-    if (slot >= ntiles) return;
-    const int tile = (int)order[slot];  // heaviest tiles first (tile_order_kernel)
+struct FwdArgs {
+    const float4* __restrict__ rec;
+    const uint32_t* __restrict__ point_list;
+    const uint2* __restrict__ ranges;
+    const uint32_t* __restrict__ order;
+    const float* __restrict__ bg;
+    int W, H, gx, ntiles, xmap;
+    float* __restrict__ out_color;
+    float* __restrict__ final_T;
+    uint32_t* __restrict__ n_contrib;
+    uint32_t* __restrict__ qlist;
+    uint32_t* __restrict__ ncon_c;
+    uint32_t* __restrict__ qcount;
+    float4* __restrict__ ckpt;
+    uint32_t* __restrict__ ck_start;
+    int chunks;
+};
+
+// between two phases of ONE wave that exchange data through LDS (a wave's LDS operations execute in order)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (compile-time ordering only: nothing waits on the global loads in flight)
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave, one quadrant (tile, q), one entry per step.  `srec`: LDS for 66 staged entries (64 + the two the pipelined
+// loop may read past a batch).
+__device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int tile, const int q, float4* __restrict__ srec) {
+    const float4* __restrict__ rec = A.rec;
+    const uint32_t* __restrict__ point_list = A.point_list;
+    const float* __restrict__ bg = A.bg;
+    const int W = A.W, H = A.H, gx = A.gx, chunks = A.chunks;
+    float* __restrict__ out_color = A.out_color;
+    float* __restrict__ final_T = A.final_T;
+    uint32_t* __restrict__ n_contrib = A.n_contrib;
+    uint32_t* __restrict__ qlist = A.qlist;
+    uint32_t* __restrict__ ncon_c = A.ncon_c;
+    uint32_t* __restrict__ qcount = A.qcount;
+    float4* __restrict__ ckpt = A.ckpt;
+    uint32_t* __restrict__ ck_start = A.ck_start;
     const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
     const int px = QX0 + (lane & 7), py = QY0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = px < W && py < H;
-    const uint2 range = ranges[tile];
+    const uint2 range = A.ranges[tile];
     const int n = (int)(range.y - range.x);
     const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;  // this quadrant's slice of qlist / gradient rows
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -71,7 +94,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + lane < n);
         const unsigned long long bal = __ballot(hit);
         const int cnt = __popcll(bal);
-        __syncthreads();
+        wave_lds_sync();
         if (hit) {
             const int slot = __popcll(bal & lt_mask);
             const uint32_t k = kcount + (uint32_t)slot;  // compacted index of this entry
@@ -81,7 +104,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
             srec[slot * 3 + 2] = s.c;
             qlist[qbase + k] = pid_g;  // record the compaction for the backward
         }
-        __syncthreads();
+        wave_lds_sync();
         kcount += (uint32_t)cnt;
         if (base + 64 + lane < n) {
             pid_g = point_list[range.x + base + 64 + lane];
@@ -123,8 +146,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
         };
         // The loop is software-pipelined by hand, two entries per trip: the LDS reads of the NEXT entry are issued
         // before the current one is evaluated.  With eight waves per SIMD the LDS latency hides behind the other waves
-        // anyway; a frame of few, long lists (a trained avatar: 150 tiles of 2000-7000 entries) runs one wave per SIMD
-        // and paid the ~100 cycles of every entry's reads in full.  (Reads one entry past the batch: srec has a 65th.)
+        // anyway; a lone wave on its SIMD paid the ~100 cycles of every entry's reads in full.  (Reads one entry past the
+        // batch: srec has a 65th.)
         auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
         auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
         auto ld_c = [&](int o) {
@@ -170,15 +193,244 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const float4* __restrict
     }
 }
 
+__global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
+    __shared__ float4 srec[66 * 3];
+    int slot, q;
+    render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
+    if (slot >= A.ntiles) return;
+    render_quadrant_1(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The forward for SMALL images (up to FWD4_MAX_TILES tiles), where one wave per quadrant leaves most of the chip idle
+// and the frame time is the longest quadrant's chain of dependent steps (a trained avatar at 512 x 512: 150 tiles with
+// lists of 2000-7000 entries, a quadrant wave alone on its SIMD for 0.3 ms).  FOUR waves per quadrant, one workgroup:
+// every wave owns 16 pixels (two rows of the quadrant) and evaluates FOUR consecutive entries per step -- lane 4 p + e
+// holds pixel p against entry j + e.  The four alphas are independent; what is sequential per pixel -- transmittance,
+// the 1e-4 stop, the last contributor -- runs down the four lanes of the pixel's quad with quad-permute DPP in exactly
+// the operation order of the one-entry-per-step kernel (T bit-identical; the colour sums associate differently:
+// per-lane partial sums, added up at the end).  A step costs ~45 VALU instructions for 4 x 16 pairs against 4 x 26 for
+// four dependent steps of 64 pairs: 1.7 x the work per pair, less than half the dependent chain; the staging pass takes
+// 256 entries of the tile's list at a time (a quarter of the batches).  Same outputs and side records (qlist, ncon_c,
+// qcount, checkpoints) as render_fwd_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float qperm(float v) {
+    // (every lane of a quad permute has a source: `old` is never kept; passing v itself spares the v_mov that sets it)
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t qperm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+#define QP_PREV 0x90   // quad_perm [0,0,1,2]: the lane before (lane 0 of the quad: itself)
+#define QP_PAIR 0x44   // quad_perm [0,1,0,1]
+#define QP_X1 0xB1     // quad_perm [1,0,3,2]
+#define QP_X2 0x4E     // quad_perm [2,3,0,1]
+#define QP_LAST 0xFF   // quad_perm [3,3,3,3]
+#define FWD4_BATCH 256
+
+// Four waves, one quadrant (tile, q), four entries per step.  `srec`: LDS for FWD4_BATCH + 8 staged entries (a batch's
+// compacted entries and four all-zero ones behind them); s_cnt / s_flag / s_lastk: four words each.
+__device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int tile, const int q, float4* __restrict__ srec,
+                                                  uint32_t* __restrict__ s_cnt, uint32_t* __restrict__ s_flag,
+                                                  uint32_t* __restrict__ s_lastk) {
+    const float4* __restrict__ rec = A.rec;
+    const uint32_t* __restrict__ point_list = A.point_list;
+    const uint2* __restrict__ ranges = A.ranges;
+    const float* __restrict__ bg = A.bg;
+    const int W = A.W, H = A.H, gx = A.gx, chunks = A.chunks;
+    float* __restrict__ out_color = A.out_color;
+    float* __restrict__ final_T = A.final_T;
+    uint32_t* __restrict__ n_contrib = A.n_contrib;
+    uint32_t* __restrict__ qlist = A.qlist;
+    uint32_t* __restrict__ ncon_c = A.ncon_c;
+    uint32_t* __restrict__ qcount = A.qcount;
+    float4* __restrict__ ckpt = A.ckpt;
+    uint32_t* __restrict__ ck_start = A.ck_start;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = lane >> 2, e = lane & 3;  // pixel of this wave (two rows of eight), entry slot of the step
+    const bool e0 = e == 0;
+    const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
+    const int px = QX0 + (p & 7), py = QY0 + 2 * wv + (p >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const bool inside = px < W && py < H;
+    const int pix_q = 16 * wv + p;  // the pixel's index in the quadrant, (py - QY0) * 8 + (px - QX0)
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;
+    const size_t quad = (size_t)(tile * 4 + q);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // T > 0 while the pixel is alive; frozen as -T (render_fwd_kernel).  The four lanes of a pixel hold the same T.
+    float T = inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;  // C: this lane's share of the pixel's colour
+    uint32_t last = 0, last_k = 0;
+    uint32_t kcount = 0;
+    int nck = 0;
+    uint32_t next_ck = BWD_CH;
+    bool live = QX0 < W && QY0 < H;  // (workgroup-uniform) the quadrant has a pixel inside the image
+
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    uint32_t pid_g = 0;
+    if (live && tid < n) {
+        pid_g = point_list[range.x + tid];
+        p0 = rec[(size_t)pid_g * 3];
+        p1 = rec[(size_t)pid_g * 3 + 1];
+        p2 = rec[(size_t)pid_g * 3 + 2];
+    }
+    for (int base = 0; base < n && live; base += FWD4_BATCH) {
+        Staged s;
+        const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + tid < n);
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();  // (the previous batch's readers of srec are done, too)
+        const uint32_t n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
+        const int cnt = (int)(n0 + n1 + n2 + n3);
+        const uint32_t woff = wv == 0 ? 0u : (wv == 1 ? n0 : (wv == 2 ? n0 + n1 : n0 + n1 + n2));
+        if (hit) {
+            const uint32_t sl = woff + (uint32_t)__popcll(bal & lt_mask);
+            s.c.w = __uint_as_float((uint32_t)(base + tid + 1));  // position in the tile's list (1-based)
+            srec[sl * 3] = s.a;
+            srec[sl * 3 + 1] = s.b;
+            srec[sl * 3 + 2] = s.c;
+            qlist[qbase + kcount + sl] = pid_g;  // record the compaction for the backward
+        }
+        if (tid < 4) {  // entries of opacity 0 behind the batch: a step always evaluates four
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            srec[(cnt + tid) * 3] = z;
+            srec[(cnt + tid) * 3 + 1] = z;
+            srec[(cnt + tid) * 3 + 2] = z;
+        }
+        __syncthreads();
+        const uint32_t kbase = kcount;  // compacted index of this batch's first entry
+        kcount += (uint32_t)cnt;
+        if (base + FWD4_BATCH + tid < n) {
+            pid_g = point_list[range.x + base + FWD4_BATCH + tid];
+            p0 = rec[(size_t)pid_g * 3];
+            p1 = rec[(size_t)pid_g * 3 + 1];
+            p2 = rec[(size_t)pid_g * 3 + 2];
+        }
+        // a chunk of the backward starts here when the previous one has its BWD_CH entries (common.h, BWD_CH)
+        if (nck + 1 < chunks && kbase >= next_ck) {
+            float s0 = C0 + qperm<QP_X1>(C0), s1 = C1 + qperm<QP_X1>(C1), s2 = C2 + qperm<QP_X1>(C2);
+            s0 += qperm<QP_X2>(s0);
+            s1 += qperm<QP_X2>(s1);
+            s2 += qperm<QP_X2>(s2);
+            if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)nck) * 64 + pix_q] = make_float4(fabsf(T), s0, s1, s2);
+            nck++;
+            if (tid == 0) ck_start[quad * (size_t)chunks + nck] = kbase;
+            next_ck = kbase + BWD_CH;
+        }
+        const char* sp = reinterpret_cast<const char*>(srec) + e * 48;
+        uint32_t idx1 = kbase + (uint32_t)e + 1u;  // compacted index of this lane's entry, 1-based
+        for (int j = 0; j < cnt; j += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(sp);
+            const float2 b = *reinterpret_cast<const float2*>(sp + 16);
+            const float4 c = *reinterpret_cast<const float4*>(sp + 32);
+            asm volatile("" ::"v"(c.w));  // one ds_read_b128 (render_fwd_kernel)
+            sp += 4 * 48;
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
+            const float G = __builtin_amdgcn_exp2f(power2);
+            const float al = fminf(0.99f, b.y * G);
+            const float a2 = (power2 <= 0.0f && al >= (1.0f / 255.0f)) ? al : 0.f;  // alpha, or 0 if the pair is rejected
+            // T before this lane's entry: T (1 - a2) of the lane before it, ... -- three rounds settle lanes 1, 2, 3
+            const float x = 1.f - a2;
+            const float xs = qperm<QP_PREV>(x);
+            float tb = T;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const float t = qperm<QP_PREV>(tb) * xs;
+                tb = e0 ? T : t;
+            }
+            const float ta = tb * x;  // == tb for a rejected pair, < 0 for a frozen pixel
+            // blended iff this entry and every entry before it in the step pass the 1e-4 test
+            uint32_t ok = (ta >= 0.0001f) ? 0xFFFFFFFFu : 0u;
+            ok &= qperm<QP_PREV>(ok);
+            ok &= qperm<QP_PAIR>(ok);
+            const float w = __uint_as_float(__float_as_uint(a2 * tb) & ok);
+            C0 += c.x * w;
+            C1 += c.y * w;
+            C2 += c.z * w;
+            last_k = (w > 0.f) ? idx1 : last_k;
+            idx1 += 4u;
+            // the pixel's T after the step: the last passing lane's, negated (frozen) unless all four passed.  (min over
+            // the bit patterns: all positive while alive, all equal once frozen)
+            uint32_t mag = (__float_as_uint(ta) & ok) | (__float_as_uint(T) & ~ok);
+            mag = min(mag, qperm<QP_X1>(mag));
+            mag = min(mag, qperm<QP_X2>(mag));
+            T = __uint_as_float(mag | (~qperm<QP_LAST>(ok) & 0x80000000u));
+        }
+        {
+            uint32_t lk = max(last_k, qperm<QP_X1>(last_k));
+            lk = max(lk, qperm<QP_X2>(lk));
+            last_k = lk;  // the pixel's last contributor so far
+            // its position in the TILE's list (n_contrib), looked up once per batch
+            if (lk > kbase) last = __float_as_uint(srec[(lk - 1u - kbase) * 3 + 2].w);
+        }
+        const bool alive = __ballot(T > 0.f) != 0ull;
+        if (lane == 0) s_flag[wv] = alive ? 1u : 0u;
+        __syncthreads();
+        live = (s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) != 0u;  // every pixel of the quadrant frozen: stop
+    }
+    {
+        const uint32_t wm = wave_max_u32(last_k);
+        if (lane == 0) s_lastk[wv] = wm;
+        __syncthreads();
+        if (tid == 0) qcount[quad] = max(max(s_lastk[0], s_lastk[1]), max(s_lastk[2], s_lastk[3]));
+        if (chunks > 1 && tid > nck && tid < chunks) ck_start[quad * (size_t)chunks + tid] = 0xFFFFFFFFu;  // never begun
+    }
+    float s0 = C0 + qperm<QP_X1>(C0), s1 = C1 + qperm<QP_X1>(C1), s2 = C2 + qperm<QP_X1>(C2);
+    s0 += qperm<QP_X2>(s0);
+    s1 += qperm<QP_X2>(s1);
+    s2 += qperm<QP_X2>(s2);
+    if (inside && e0) {
+        const size_t HW = (size_t)H * W;
+        const size_t pid = (size_t)py * W + px;
+        const float Tf = fabsf(T);
+        final_T[pid] = Tf;
+        n_contrib[pid] = last;
+        ncon_c[pid] = last_k;
+        out_color[pid] = s0 + Tf * bg[0];
+        out_color[HW + pid] = s1 + Tf * bg[1];
+        out_color[2 * HW + pid] = s2 + Tf * bg[2];
+    }
+}
+
+// Small images: one workgroup of four waves per quadrant.  Quadrants of tiles whose list is long against the frame's
+// total (tile_order_kernel marks them in the launch order) are rendered by all four waves, four entries per step; the
+// others by the first wave alone, as on large images -- there the chip is busy anyway and the one-entry step does the
+// same work in 0.6 x the instructions.
+__global__ __launch_bounds__(FWD4_BATCH) void render_fwd_small_kernel(const FwdArgs A) {
+    __shared__ float4 srec[(FWD4_BATCH + 8) * 3];
+    __shared__ uint32_t s_cnt[4], s_flag[4], s_lastk[4];
+    int slot, q;
+    render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
+    if (slot >= A.ntiles) return;
+    const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
+    if (ov >> 31) {
+        render_quadrant_4(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
+    } else if (threadIdx.x < 64) {
+        render_quadrant_1(A, (int)ov, q, srec);  // (no workgroup barrier inside: the other waves have left)
+    }
+}
+
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
                           const QuadLists& ql, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s,
-                       reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg,
-                       W, H, gx, gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt,
-                       ql.ck_start, ql.ckpt ? ql.chunks : 1);
+    const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
+                    gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
+                    ql.ckpt ? ql.chunks : 1};
+    // small images: four waves per quadrant, all used where tile_order_kernel marked the tile's list as long.  By image
+    // size alone, so that a configuration always runs the same kernel.
+    if (forward_small_image(gx * gy))
+        hipLaunchKernelGGL(render_fwd_small_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(FWD4_BATCH), 0, s, A);
+    else
+        hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s, A);
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }

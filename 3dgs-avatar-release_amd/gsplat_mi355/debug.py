@@ -69,6 +69,8 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
             n_contrib=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 1), 4 * W * H, np.uint32).reshape(H, W),
             final_T=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 2), 4 * W * H, np.float32).reshape(H, W),
             qcount=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 3), 16 * gx * gy, np.uint32).reshape(-1, 4),
+            # launch order of the tiles (heaviest first); bit 31: rendered by four waves per quadrant (small images)
+            order=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 5), 4 * gx * gy, np.uint32),
         )
     # the tile of every list entry: the lists are stored tile after tile, so the ranges say it (upstream keeps the tile
     # id in the high half of its sort keys)

@@ -252,7 +252,8 @@ int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, d
  *  binning: 0 point_list u32[D] (tile after tile, (depth, index) order inside a tile; tile t owns ranges[t] of it)
  *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W]
  *           3 per-quadrant compacted count up to the last contributor u32[tiles,4]
- *           4 per-pixel last contributor in compacted coordinates u32[H,W] */
+ *           4 per-pixel last contributor in compacted coordinates u32[H,W]
+ *           5 launch order of the tiles u32[tiles], heaviest first; bit 31 = rendered by four waves per quadrant */
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
 int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
