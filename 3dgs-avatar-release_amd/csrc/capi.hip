@@ -21,6 +21,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_NT_STORES].store(1);
     g_tune[GS_TUNE_BWD_CHUNKS].store(1);
     g_tune[GS_TUNE_FWD4].store(1);
+    g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -636,6 +637,7 @@ int gs_tuning(const char* name, int value) {
     if (!name) return GS_E_BAD_ARG;
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
+    if (strcmp(name, "small_tiles") == 0) { g_tune[GS_TUNE_SMALL_TILES].store(value); return GS_OK; }  // changes the image state's size
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }

@@ -117,6 +117,10 @@ static inline int bin_segments(const BinGrid& G, int P) {
     return s < G.nseg_max ? s : G.nseg_max;
 }
 
+// process-wide tuning switches (gs_tuning)
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_COUNT = 8 };
+int gs_tune_get(int key);
+
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
 // entries -- leaves most SIMDs idle while a handful of waves walk their quadrant's list alone, one dependent step after
 // the other.  The forward therefore checkpoints the per-pixel compositing state (T, C) at the first batch boundary at
@@ -151,7 +155,7 @@ static inline ImgLayout img_layout(int W, int H) {
     L.tile_tot = take(nt * 4);                     // pairs per tile
     L.tile_loc = take(nt * 4);                     // ... and their exclusive prefix inside the tile's group of 64 tiles
     L.grp_sum = take((nt / 64 + 1) * 4);           // pairs per group of 64 tiles
-    L.bwd_chunks = nt <= BWD_CHUNK_MAX_TILES ? BWD_KMAX : 1;
+    L.bwd_chunks = nt <= (size_t)gs_tune_get(GS_TUNE_SMALL_TILES) ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
     L.ck_start = take(nt * 4 * (size_t)L.bwd_chunks * 4);  // [quadrant][chunk]: first compacted entry of the chunk, ~0 = none
@@ -192,8 +196,6 @@ __device__ __forceinline__ uint32_t pair_count(const PairCount pc) {
 }
 
 // Process-wide tuning switches (gs_tuning; experiments and A/B runs, not part of the drop-in surface).
-int gs_tune_get(int key);
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_COUNT = 8 };
 
 // Workgroup -> (tile slot, quadrant) of the render kernels.  Workgroups are dealt round-robin over the 8 XCDs (each
 // with its own L2), so with the plain mapping (slot = b / 4, quadrant = b % 4) the four quadrant waves of one tile land
@@ -210,7 +212,7 @@ __device__ __forceinline__ void render_block_map(int b, int xmap, int* slot, int
     }
 }
 // the forward runs four waves per quadrant, and tile_order_kernel marks the tiles that use them all (render_fwd.hip)
-static inline bool forward_small_image(int ntiles) { return ntiles <= FWD4_MAX_TILES && gs_tune_get(GS_TUNE_FWD4) != 0; }
+static inline bool forward_small_image(int ntiles) { return ntiles <= gs_tune_get(GS_TUNE_SMALL_TILES) && gs_tune_get(GS_TUNE_FWD4) != 0; }
 static inline int render_grid_blocks(int ntiles, int xmap) { return xmap ? ((ntiles + 7) / 8) * 32 : ntiles * 4; }
 
 struct StageScope {
