@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
                                                           uint32_t* __restrict__ order, uint2* __restrict__ ranges_out,
                                                           const uint32_t* __restrict__ loc,
                                                           const uint32_t* __restrict__ grp, const PairCount pc,
-                                                          const FillJob fill, const int mark_wide) {
+                                                          const FillJob fill, const LongLists ll) {
     if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
@@ -568,9 +568,34 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
     // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
     uint32_t wide_from = 0xFFFFFFFFu;
-    if (mark_wide && mode == 2) {
+    if (mode == 2) {
         const unsigned long long D = *pc.dev;
         wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
+        if (ll.stats) {
+            // how many such tiles, and the longest list: for the caller's choice of GsFwdArgs.long_lists next frame
+            uint32_t nlong = 0;
+            if (HELD) {
+#pragma unroll
+                for (int i = 0; i < PER; i++) {
+                    if (i * 1024 >= ntiles) break;
+                    nlong += (i * 1024 + tid < ntiles && held[i] > wide_from) ? 1u : 0u;
+                }
+            } else {
+                for (int t = tid; t < ntiles; t += 1024) nlong += tile_work(ranges, keys, mode, t) > wide_from ? 1u : 0u;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nlong += (uint32_t)__shfl_xor((int)nlong, d, 64);
+            __syncthreads();  // (wsum is free again: the scan above has read it)
+            if (lane == 0) wsum[wid] = nlong;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < 16; w++) tot += wsum[w];
+                __hip_atomic_store(&ll.stats[0], (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&ll.stats[1], (long long)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        if (!ll.mark) wide_from = 0xFFFFFFFFu;
     }
     if (HELD) {
 #pragma unroll
@@ -588,24 +613,24 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 }
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, uint32_t* ranges_out,
-                      const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, int debug, hipStream_t s) {
-    const int mark_wide = (mode == 2 && forward_small_image(ntiles)) ? 1 : 0;
+                      const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, LongLists ll, int debug,
+                      hipStream_t s) {
     // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
     const size_t pieces = (fill.quads + 1023) / 1024;
     const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, mark_wide);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, ll);
     else
         hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, mark_wide);
+                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, ll);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }
 
 // The whole tile binning of one frame: counting pass, prefixes, ranges + launch order, writing pass.
 int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s) {
+                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, int debug, hipStream_t s) {
     uint32_t* seg_cnt = tc.seg_cnt;
     const BinGrid G = bin_grid(gx, gy);
     const int nseg = bin_segments(G, P);  // segments of about equal work (segment_bounds)
@@ -628,7 +653,7 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P,
     GS_LAUNCH_CHECK("seg_prefix", debug, s); }
     { StageScope sc_("ranges_order", s);
     const int rc = launch_tile_order(nullptr, tc.tile_tot, 2, ntiles, order, ranges, tc.tile_loc, tc.grp_sum, pc,
-                                     FillJob{nullptr, 0}, debug, s);
+                                     FillJob{nullptr, 0}, ll, debug, s);
     if (rc != GS_OK) return rc; }
     if (pc.cap > 0) {
         StageScope sc_("tile_write", s);

@@ -99,6 +99,11 @@ int gs_image_bytes(int32_t W, int32_t H, size_t* out) {
     *out = img_layout(W, H).total;
     return GS_OK;
 }
+int gs_image_bytes_for(const GsFwdArgs* a, size_t* out) {
+    if (!a || !out || a->W <= 0 || a->H <= 0) return GS_E_BAD_ARG;
+    *out = img_layout(a->W, a->H, a->long_lists).total;
+    return GS_OK;
+}
 int gs_binning_bytes(int64_t D, int32_t W, int32_t H, size_t* out) {
     if (!out || D < 0 || W <= 0 || H <= 0) return GS_E_BAD_ARG;
     if (D > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
@@ -119,7 +124,7 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     if (rc != GS_OK) return rc;
     if (!geom || !img || (a->P > 0 && !radii)) return GS_E_BAD_ARG;
     const GeomLayout L = geom_layout(a->P);
-    const ImgLayout I = img_layout(a->W, a->H);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
     if (geom_bytes < L.total || img_bytes < I.total) return GS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* g = (char*)geom;
@@ -189,7 +194,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     if (!geom || !img || !out_color || cap < 0 || (cap > 0 && !binning)) return GS_E_BAD_ARG;
     if (cap > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const GeomLayout L = geom_layout(a->P);
-    const ImgLayout I = img_layout(a->W, a->H);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
     const BinLayout B = bin_layout(cap);
     if (geom_bytes < L.total || img_bytes < I.total || (cap > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -209,14 +214,15 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
                                TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), (uint32_t*)(im + I.tile_loc),
                                           (uint32_t*)(im + I.grp_sum)},
                                ranges, (uint32_t*)(im + I.order),
-                               cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc, a->debug, s);
+                               cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc,
+                               LongLists{forward_small_image(ntiles, a->long_lists) ? 1 : 0, (long long*)a->frame_stats}, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
         StageScope sc_("ranges_order", s);
         rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), nullptr, nullptr, nullptr, pc,
-                               FillJob{nullptr, 0}, a->debug, s);
+                               FillJob{nullptr, 0}, LongLists{0, nullptr}, a->debug, s);
         if (rc != GS_OK) return rc;
     }
     QuadLists ql;
@@ -224,6 +230,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+    ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     { StageScope sc_("render_fwd", s);
@@ -303,7 +310,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     if (rc != GS_OK) return rc;
     if (!geom_src || !img_src || !geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
     const GeomLayout L = geom_layout(a->P);
-    const ImgLayout I = img_layout(a->W, a->H);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
     const BinLayout B = bin_layout(D);
     if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -329,6 +336,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+    ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     { StageScope sc_("render_fwd", s);
@@ -347,7 +355,7 @@ int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, floa
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!img || !opacity) return GS_E_BAD_ARG;
-    const ImgLayout I = img_layout(a->W, a->H);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
     if (img_bytes < I.total) return GS_E_WORKSPACE;
     return launch_opacity_image((const float*)((const char*)img + I.final_T), a->bg, a->W, a->H, opacity, (hipStream_t)stream);
 }
@@ -365,7 +373,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
     if (a->P > 0 && a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return GS_E_BAD_ARG;
     if (gr->dL_drotations && ((uintptr_t)gr->dL_drotations & 15u)) return GS_E_BAD_ARG;  // written as float4
     const GeomLayout L = geom_layout(a->P);
-    const ImgLayout I = img_layout(a->W, a->H);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
     const BinLayout B = bin_layout(D);
     size_t need = 0;
     gs_backward_scratch_bytes(D, a->P, a->W, a->H, &need);
@@ -382,6 +390,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
         ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+    ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
         ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
@@ -389,7 +398,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr, nullptr, nullptr,
-                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1}, a->debug, s); }
+                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1}, LongLists{0, nullptr},
+                               a->debug, s); }
         if (rc != GS_OK) return rc;
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,

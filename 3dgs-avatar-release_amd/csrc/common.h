@@ -138,7 +138,11 @@ struct ImgLayout {
     size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, ck_start, total;
     int gx, gy, bwd_chunks;
 };
-static inline ImgLayout img_layout(int W, int H) {
+// `long_lists`: GsFwdArgs.long_lists (the few-long-lists machinery on an image of any size)
+static inline bool few_long_lists_mode(int ntiles, int long_lists) {
+    return ntiles <= gs_tune_get(GS_TUNE_SMALL_TILES) || long_lists != 0;
+}
+static inline ImgLayout img_layout(int W, int H, int long_lists = 0) {
     ImgLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
@@ -155,7 +159,7 @@ static inline ImgLayout img_layout(int W, int H) {
     L.tile_tot = take(nt * 4);                     // pairs per tile
     L.tile_loc = take(nt * 4);                     // ... and their exclusive prefix inside the tile's group of 64 tiles
     L.grp_sum = take((nt / 64 + 1) * 4);           // pairs per group of 64 tiles
-    L.bwd_chunks = nt <= (size_t)gs_tune_get(GS_TUNE_SMALL_TILES) ? BWD_KMAX : 1;
+    L.bwd_chunks = few_long_lists_mode((int)nt, long_lists) ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
     L.ck_start = take(nt * 4 * (size_t)L.bwd_chunks * 4);  // [quadrant][chunk]: first compacted entry of the chunk, ~0 = none
@@ -212,7 +216,7 @@ __device__ __forceinline__ void render_block_map(int b, int xmap, int* slot, int
     }
 }
 // the forward runs four waves per quadrant, and tile_order_kernel marks the tiles that use them all (render_fwd.hip)
-static inline bool forward_small_image(int ntiles) { return ntiles <= gs_tune_get(GS_TUNE_SMALL_TILES) && gs_tune_get(GS_TUNE_FWD4) != 0; }
+static inline bool forward_small_image(int ntiles, int long_lists) { return few_long_lists_mode(ntiles, long_lists) && gs_tune_get(GS_TUNE_FWD4) != 0; }
 static inline int render_grid_blocks(int ntiles, int xmap) { return xmap ? ((ntiles + 7) / 8) * 32 : ntiles * 4; }
 
 struct StageScope {
@@ -263,8 +267,11 @@ int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* 
 int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist,
                      uint32_t* chunk_pairs, int P, int debug, hipStream_t s);
 struct TileCounts { uint32_t *seg_cnt, *tile_tot, *tile_loc, *grp_sum; };
+// what the tile-order launch of the forward also does: mark the tiles whose list is long against the frame's total in
+// the launch order (bit 31; render_fwd.hip) and report how many there are and the longest list (GsFwdArgs.frame_stats)
+struct LongLists { int mark; long long* stats; };
 int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, int debug, hipStream_t s);
+                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, int debug, hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)
 int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
@@ -310,13 +317,14 @@ __device__ __forceinline__ void store_stream(uint4* p, uint4 v) {
 // mode 0: work = ranges[t].y - ranges[t].x; mode 1: work = keys[4 t .. 4 t + 3] summed; mode 2: work = keys[t] = the
 // tile's pair count, and the tile ranges are written first from (loc, grp): see tile_order_kernel
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order,
-                      uint32_t* ranges_out, const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, int debug,
-                      hipStream_t s);
+                      uint32_t* ranges_out, const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, LongLists ll,
+                      int debug, hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
+    int four_waves = 0;      // forward: four waves per quadrant, all used on the tiles marked in the launch order
     float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
     uint32_t* ck_start = nullptr;  // [quadrant][chunks]: compacted index every chunk starts at
     int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)

@@ -425,9 +425,9 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
                     ql.ckpt ? ql.chunks : 1};
-    // small images: four waves per quadrant, all used where tile_order_kernel marked the tile's list as long.  By image
-    // size alone, so that a configuration always runs the same kernel.
-    if (forward_small_image(gx * gy))
+    // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
+    // tile_order_kernel marked the tile's list as long
+    if (ql.four_waves)
         hipLaunchKernelGGL(render_fwd_small_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(FWD4_BATCH), 0, s, A);
     else
         hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s, A);

@@ -161,7 +161,22 @@ def _f32c(t, name):
 _TILE_RECT = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
 
 
-def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep):
+# GsFwdArgs.long_lists: the machinery for frames of few, long tile lists (a trained avatar: four waves per quadrant in the
+# forward on the tiles whose list is long against the frame's total, backward in chunks) is always used on images of up
+# to 2048 tiles; on larger ones "auto" turns it on when the PREVIOUS frame of the same shape had such tiles (the forward
+# reports them in a pinned word), "1" / "0" force it on / off.  Outputs of the two settings agree to fp32 rounding.
+_LONG_LISTS = os.environ.get("GSPLAT_LONG_LISTS", "auto")
+_frame_stats = {}  # (device index, P, W, H) -> pinned int64[2]: [tiles with a long list, longest list] of the last frame
+
+
+def _stats_words(key):
+    st = _frame_stats.get(key)
+    if st is None:
+        st = _frame_stats[key] = torch.zeros(2, dtype=torch.int64).pin_memory()
+    return st
+
+
+def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep, long_lists=None):
     a = _lib.GsFwdArgs()
     P = int(means3D.shape[0])
     a.P = P
@@ -187,6 +202,11 @@ def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotatio
     a.prefiltered = int(bool(settings.prefiltered))
     a.debug = int(bool(settings.debug))
     a.tile_rect = _TILE_RECT
+    st = _stats_words((dev.index, P, a.W, a.H))
+    if long_lists is None:  # a forward: decided from the previous frame of this shape (stale or missing words: a guess as good)
+        long_lists = 1 if (_LONG_LISTS == "1" or (_LONG_LISTS == "auto" and int(st[0]) > 0)) else 0
+        a.frame_stats = st.data_ptr()
+    a.long_lists = int(long_lists)
     return a
 
 
@@ -254,7 +274,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = torch.cuda.current_stream(dev)
             sptr = ctypes.c_void_p(stream.cuda_stream)
             geom_bytes = _lib.nbytes(L.gs_geom_bytes, P)
-            img_bytes = _lib.nbytes(L.gs_image_bytes, W, H)
+            img_bytes = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
             geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
@@ -327,6 +347,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             _lib.check(L.gs_opacity_image(ctypes.byref(a), img.data_ptr(), img.numel(), opacity.data_ptr(), sptr))
         ctx.raster_settings = raster_settings
+        ctx.long_lists = int(a.long_lists)  # the backward must be told the same (GsFwdArgs.long_lists)
         ctx.num_rendered = num_rendered  # the frame's pair count (upstream's num_rendered)
         ctx.capacity = capacity          # pairs the binning state is carved for (>= num_rendered): what the backward is given
         ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -372,7 +393,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
                            scales if has_sr else None, rotations if has_sr else None,
-                           cov3Ds_precomp if has_cov else None, keep)
+                           cov3Ds_precomp if has_cov else None, keep, long_lists=ctx.long_lists)
             sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             scratch_bytes = _lib.nbytes(L.gs_backward_scratch_bytes, D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)

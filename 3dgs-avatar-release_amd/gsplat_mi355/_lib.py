@@ -16,7 +16,8 @@ class GsFwdArgs(ctypes.Structure):
         ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p),
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("campos", c_void_p),
         ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
-        ("prefiltered", c_int32), ("debug", c_int32), ("tile_rect", c_int32),
+        ("prefiltered", c_int32), ("debug", c_int32), ("tile_rect", c_int32), ("long_lists", c_int32),
+        ("frame_stats", c_void_p),
     ]
 
 
@@ -31,7 +32,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
-           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve"]
+           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_ADAM_MAX_TENSORS = 16
@@ -61,6 +62,7 @@ def load():
         L = ctypes.CDLL(LIB_PATH)
         L.gs_geom_bytes.argtypes = [c_int32, POINTER(c_size_t)]
         L.gs_image_bytes.argtypes = [c_int32, c_int32, POINTER(c_size_t)]
+        L.gs_image_bytes_for.argtypes = [POINTER(GsFwdArgs), POINTER(c_size_t)]
         L.gs_binning_bytes.argtypes = [c_int64, c_int32, c_int32, POINTER(c_size_t)]
         L.gs_backward_scratch_bytes.argtypes = [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]
         L.gs_forward_preprocess.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,

@@ -33,7 +33,7 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
         stream = torch.cuda.current_stream(dev)
         sptr = ctypes.c_void_p(stream.cuda_stream)
         gb = _lib.nbytes(L.gs_geom_bytes, P)
-        ib = _lib.nbytes(L.gs_image_bytes, W, H)
+        ib = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
         geom = torch.zeros(gb, dtype=torch.uint8, device=dev)
         img = torch.zeros(ib, dtype=torch.uint8, device=dev)
         radii = torch.zeros(P, dtype=torch.int32, device=dev)

@@ -67,6 +67,16 @@ typedef struct GsFwdArgs {
                           * (half-widths sqrt(2 ln(255 opacity) Sigma_xx), sqrt(... Sigma_yy)), intersected with the
                           * square: every tile left out contributes nothing to any pixel, so colour, radii and all
                           * gradients are those of mode 0 while num_rendered and the tile lists are ~40 % shorter */
+    int32_t long_lists;  /* 0: the machinery for frames of few, long tile lists (four waves per quadrant in the forward on
+                          * the tiles whose list is long against the frame's total, backward in chunks from checkpoints of
+                          * the forward) is used on images of up to 2048 tiles only.  1: on this image whatever its size --
+                          * the image state is then larger (gs_image_bytes_for).  A frame that fills the chip with one wave
+                          * per quadrant is ~10 % slower with it, one of few long lists (a trained avatar filling a sixth of
+                          * 1024 x 1024) 1.45 x faster; outputs agree to fp32 rounding.  The SAME value must be passed to the
+                          * backward (and to gs_forward_shared) of a forward */
+    int64_t* frame_stats; /* NULL, or two words the forward writes (device-visible host memory or device memory), for the
+                          * caller to choose long_lists for the NEXT frame: [0] tiles whose list is long against this
+                          * frame's total (the tiles the four-wave forward takes), [1] the longest tile list */
 } GsFwdArgs;
 
 /* The eight gradient outputs of upstream `rasterize_gaussians_backward`, in the order the
@@ -257,6 +267,8 @@ int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, d
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
 int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
+/* size of the image state for a call with these arguments (W, H, long_lists); gs_image_bytes(W, H) = long_lists 0 */
+int gs_image_bytes_for(const GsFwdArgs* a, size_t* out);
 
 /* ---- per-stage timing (the reference only timed whole calls with CUDA events: render.py:46-62,
  * train.py:79-88,181-185).  When enabled (process-wide: autograd runs the backward on its own host thread), every stage launched by this library is

@@ -49,6 +49,25 @@ def test_size_functions_and_status_strings(lib):
     assert b"gfx950" in L.gs_build_info()
 
 
+def test_image_state_size_follows_the_long_lists_flag(lib):
+    """GsFwdArgs.long_lists: the checkpoints of the chunked backward are part of the image state on images of up to 2048
+    tiles whatever the flag says, on larger ones only with the flag (gs_image_bytes_for); gs_image_bytes = flag 0."""
+    L = lib.load()
+    a = lib.GsFwdArgs()
+    for (W, H), always in (((512, 512), True), ((1024, 1024), False)):
+        a.W, a.H = W, H
+        a.long_lists = 0
+        plain = lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
+        assert plain == lib.nbytes(L.gs_image_bytes, W, H)
+        a.long_lists = 1
+        flagged = lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
+        tiles = (W // 16) * (H // 16)
+        if always:
+            assert flagged == plain >= tiles * 4 * 7 * 64 * 16
+        else:
+            assert flagged >= plain + tiles * 4 * 7 * 64 * 16
+
+
 def test_argument_validation_without_a_device(lib):
     """Exclusivity / null checks are done on the host before any HIP call."""
     L = lib.load()

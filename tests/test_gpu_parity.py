@@ -377,6 +377,55 @@ def test_long_lists_on_a_small_image_backward_in_chunks(oracle, with_opacity):
             _bulk_close(a[k], want[ok].reshape(a[k].shape), tol=5e-5, frac=2e-3, name="chunked " + k)
 
 
+def test_long_lists_on_a_large_image_follow_the_previous_frames_statistics(oracle, monkeypatch):
+    """Above 2048 tiles the few-long-lists machinery (four-wave forward, backward in chunks) is the caller's choice
+    (GsFwdArgs.long_lists): the wrapper takes it from the statistics the forward of the PREVIOUS frame of the same shape
+    left in a pinned word.  A trained-avatar shaped frame on 800 x 800 (2500 tiles): the first frame runs without it and
+    reports its long lists, the second runs with it; both match the oracle, and each other to fp32 rounding."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 80000, 800, 800
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=6, layout="body")
+    cloud.opacity = cloud.opacity * 0.3
+    bg = (0.3, 0.2, 0.1)
+    sc = helpers.oracle_scene(cloud, cam, bg=bg)
+    fw = oracle.forward(sc)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9))
+    want = oracle.backward(sc, fw, gimg.numpy())
+    monkeypatch.setattr(dgr, "_LONG_LISTS", "auto")
+    dgr._frame_stats.pop((0, n, W, H), None)
+
+    def frame():
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        color, radii = GaussianRasterizer(_settings(cam, cloud, bg, dev))(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        mode = color.grad_fn.long_lists
+        (color * gimg.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        out = dict(color=color.detach(), means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad)
+        out.update({k: v.grad for k, v in kw.items()})
+        return mode, {k: v.cpu().numpy() for k, v in out.items()}
+
+    m0, a = frame()
+    st = dgr._frame_stats[(0, n, W, H)]
+    assert m0 == 0 and int(st[0]) > 0 and int(st[1]) > 1000  # long lists seen and reported
+    m1, b = frame()
+    assert m1 == 1
+    assert np.abs(a["color"] - b["color"]).max() <= 3e-6
+    names = dict(shs="sh", scales="scales", rotations="rotations", means3D="means3D", means2D="means2D", opacities="opacities")
+    for k in names:
+        scale = np.abs(a[k]).max()
+        assert np.abs(a[k] - b[k]).max() <= 3e-6 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
+        _bulk_close(b[k], want[names[k]].reshape(b[k].shape), tol=5e-5, frac=2e-3, name="long lists " + k)
+    _bulk_close(b["color"], fw["color"], frac=1e-3, name="color")
+    monkeypatch.setattr(dgr, "_LONG_LISTS", "0")
+    m2, c = frame()
+    assert m2 == 0 and all(np.array_equal(a[k], c[k]) for k in a)  # forced off: the first frame's bits again
+
+
 @pytest.mark.parametrize("W,H", [(1500, 90), (90, 1500), (1100, 1090), (2070, 40)])
 def test_tile_lists_across_tile_block_boundaries_with_screen_filling_gaussians(oracle, tile_rect, W, H):
     """The tile lists are built per block of 64 x 4 tiles and per segment of the depth ranking (binning.hip): image shapes
