@@ -1223,6 +1223,53 @@ def test_random_small_scenes_against_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_random_dense_small_scenes_against_oracle(oracle):
+    """Fuzz of the few-long-lists paths (four-wave forward on marked tiles, backward in chunks): ten random DENSE small
+    scenes -- thousands of entries per tile on ragged images of a few dozen tiles, thin-shell and box clouds, opaque to
+    translucent, every SH degree -- radii exact, image and all gradients within the float bar, and the tile marks /
+    chunk checkpoints actually in play."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    marked = chunked = 0
+    for trial in range(10):
+        n = int(rng.choice([6000, 12000, 25000]))
+        W, H = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+        deg = int(rng.integers(0, 4))
+        layout = "body" if trial % 2 == 0 else "box"
+        cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=deg, seed=300 + trial, layout=layout,
+                                              scale_mul=float(rng.uniform(0.6, 1.5)))
+        cloud.opacity = cloud.opacity * float(rng.choice([0.1, 0.4, 1.0]))
+        bg = tuple(float(v) for v in rng.random(3))
+        sc = helpers.oracle_scene(cloud, cam, bg=bg)
+        fw = oracle.forward(sc)
+        gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(trial))
+        want = oracle.backward(sc, fw, gimg.numpy())
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        settings = _settings(cam, cloud, bg, dev)
+        color, radii = GaussianRasterizer(settings)(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        (color * gimg.to(dev)).sum().backward()
+        st = debug.forward_state(settings, means3D.detach(), opac.detach(), **{k: v.detach() for k, v in kw.items()})
+        marked += int((st["image"]["order"] >> 31).sum())
+        chunked += int((st["image"]["qcount"] > 256).sum())
+        tag = "trial %d (n=%d %dx%d deg %d %s)" % (trial, n, W, H, deg, layout)
+        assert np.array_equal(radii.cpu().numpy(), fw["geom"]["radii"]), tag
+        assert np.array_equal(st["binning"]["point_list"], fw["binning"]["point_list"]), tag
+        _bulk_close(color.detach().cpu().numpy(), fw["color"], frac=1e-3, name=tag + " color")
+        assert (st["image"]["n_contrib"] != fw["image"]["n_contrib"]).mean() < 2e-3, tag
+        got = dict(means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad, sh=kw["shs"].grad,
+                   scales=kw["scales"].grad, rotations=kw["rotations"].grad)
+        for name, gt in got.items():
+            w = want[name].reshape(gt.shape)
+            _bulk_close(gt.cpu().numpy(), w, tol=5e-5, frac=2e-3, name=tag + " " + name)
+    assert marked > 20 and chunked > 20  # the paths under test did run
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bgval", [(0.0, 0.0, 0.0), (0.3, 0.6, 0.1)])
 def test_fused_opacity_render_matches_the_second_rasterizer_call(oracle, bgval):
     """N1, second form: rasterizer(..., with_opacity=True) returns the image the reference gets from its second call
