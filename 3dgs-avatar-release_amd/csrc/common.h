@@ -127,8 +127,8 @@ int gs_tune_get(int key);
 // least BWD_CH compacted entries after the previous checkpoint, notes the compacted index it stands at (ck_start), and
 // the backward runs one wave per (quadrant, chunk), each starting from its checkpoint.  Only for images of up to
 // BWD_CHUNK_MAX_TILES tiles: a larger frame fills the chip with one wave per quadrant.
-#define BWD_CH 256
-#define BWD_KMAX 8   // chunks per quadrant; the last one takes whatever lies beyond the last checkpoint
+#define BWD_CH 128
+#define BWD_KMAX 16  // chunks per quadrant; the last one takes whatever lies beyond the last checkpoint
 #define BWD_CHUNK_MAX_TILES 2048
 #define FWD4_MAX_TILES 2048   // the forward runs four waves per quadrant up to this many tiles (render_fwd.hip)
 #define FWD4_MIN_LIST 512u    // ... all four on the tiles whose list is longer than this and than (frame's pairs) / FWD4_TOTAL_DIV

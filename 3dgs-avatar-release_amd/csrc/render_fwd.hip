@@ -312,20 +312,22 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
         }
-        // a chunk of the backward starts here when the previous one has its BWD_CH entries (common.h, BWD_CH)
-        if (nck + 1 < chunks && kbase >= next_ck) {
+        // a chunk of the backward starts where the previous one has its BWD_CH entries (common.h, BWD_CH): at a step
+        // boundary, here also in the middle of a batch (a batch holds up to 256 entries)
+        auto checkpoint = [&](const uint32_t k0) {
             float s0 = C0 + qperm<QP_X1>(C0), s1 = C1 + qperm<QP_X1>(C1), s2 = C2 + qperm<QP_X1>(C2);
             s0 += qperm<QP_X2>(s0);
             s1 += qperm<QP_X2>(s1);
             s2 += qperm<QP_X2>(s2);
             if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)nck) * 64 + pix_q] = make_float4(fabsf(T), s0, s1, s2);
             nck++;
-            if (tid == 0) ck_start[quad * (size_t)chunks + nck] = kbase;
-            next_ck = kbase + BWD_CH;
-        }
+            if (tid == 0) ck_start[quad * (size_t)chunks + nck] = k0;
+            next_ck = k0 + BWD_CH;
+        };
         const char* sp = reinterpret_cast<const char*>(srec) + e * 48;
         uint32_t idx1 = kbase + (uint32_t)e + 1u;  // compacted index of this lane's entry, 1-based
         for (int j = 0; j < cnt; j += 4) {
+            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);  // (workgroup-uniform)
             const float4 a = *reinterpret_cast<const float4*>(sp);
             const float2 b = *reinterpret_cast<const float2*>(sp + 16);
             const float4 c = *reinterpret_cast<const float4*>(sp + 32);

@@ -59,8 +59,9 @@ WORKLOADS = {
     # the 512 x 512 image, mostly opaque) next to config 4's initial-state cloud -- few, long tile lists
     "avatar": (200000, 512, 512, 3, 0.0, True),
     "avatar1k": (200000, 1024, 1024, 3, 0.0, True),  # the same cloud at ZJU-MoCap's native resolution
+    "avatar50k": (50000, 512, 512, 3, 0.0, True),    # the reference's initial point count (dataset/zjumocap.py:412)
 }
-WORKLOAD_LAYOUT = {"avatar": "body", "avatar1k": "body"}
+WORKLOAD_LAYOUT = {"avatar": "body", "avatar1k": "body", "avatar50k": "body"}
 
 # kernel (rocprofv3 name) -> bench stage it belongs to
 KERNEL_STAGE = {"preprocess_kernel": "preprocess", "render_fwd_kernel": "render_fwd", "render_bwd_kernel": "render_bwd",
