@@ -27,9 +27,12 @@ static inline size_t sort_table_words(size_t n) {
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
 #define DS_ITEMS 2048  // keys per workgroup in the counting / scattering passes of the bucket depth sort
-// depth buckets for P Gaussians: ~128 per bucket for a uniform spread, a multiple of 64, 256 ... 4096
+#ifndef DS_PER_BUCKET
+#define DS_PER_BUCKET 64  // (128: config 3 - 0.5 %, a thin-shell cloud -- depths bunched at two surfaces -- - 2.4 %)
+#endif
+// depth buckets for P Gaussians: ~64 per bucket for a uniform spread, a multiple of 64, 256 ... 4096
 static inline int ds_buckets(int P) {
-    int nb = (P / 128 + 63) / 64 * 64;
+    int nb = (P / DS_PER_BUCKET + 63) / 64 * 64;
     return nb < 256 ? 256 : (nb > 4096 ? 4096 : nb);
 }
 

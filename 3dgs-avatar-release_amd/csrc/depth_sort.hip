@@ -8,7 +8,7 @@
 // extra bucket behind all others (nothing downstream looks at their order).  (2) prefix: per bucket over the workgroups,
 // and over the buckets.  (3) scatter: (key << 32 | index) to the bucket's slice, any order inside it.  (4) one workgroup
 // per bucket sorts its slice (bitonic network on the 64-bit composites in LDS): equal keys end up in ascending index
-// order, i.e. the order of a STABLE sort on the key.  NB ~ P / 128 buckets: a bucket holds ~128 keys for a uniform
+// order, i.e. the order of a STABLE sort on the key.  NB ~ P / 64 buckets (at most 4096): a bucket holds ~64 keys for a uniform
 // spread of depths; one that holds more than the LDS takes (a scene with most Gaussians at one depth) is sorted in
 // global memory by the same network -- slow (milliseconds for 200k keys in one bucket) but exact.
 #include "common.h"
@@ -280,7 +280,7 @@ __device__ __forceinline__ void rank_emit(const RankOut& ro, uint32_t r, bool va
     if (sB != 0u) { chunk_flush(ro, acc); acc.cur = cA + 1u; acc.sum = sB; }
 }
 
-// One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~128
+// One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~64
 // per bucket): the network runs in LDS without workgroup barriers -- a wave's LDS operations execute in order.
 #define DS_WAVE_CAP 1024
 __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned long long* __restrict__ tmp,
