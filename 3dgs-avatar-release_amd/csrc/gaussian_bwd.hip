@@ -7,6 +7,10 @@
 #include "gs_math.h"
 #include "blend.h"
 
+#ifndef GB_THREADS
+#define GB_THREADS 256  // Gaussians per workgroup of the per-Gaussian backward (its SH tile: 49 floats per Gaussian in LDS)
+#endif
+
 // Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous span of pairs,
 // TWO PAIRS PER STEP -- lane j of the group reads 16 bytes: pair slot j >> 3, quadrant (j >> 1) & 3, half j & 1 of the
 // 32-byte row -- so the eight lanes of a pair read one contiguous 128-byte line (a Gaussian-per-lane-group walk in which
@@ -332,8 +336,8 @@ int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const flo
                        reinterpret_cast<const float4*>(rec), tiles, q8,
                        reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
-    const size_t lds = a.shs ? (size_t)256 * ((3 * a.M) | 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, a.P, a.sh_degree, a.M, a.means3D,
+    const size_t lds = a.shs ? (size_t)GB_THREADS * ((3 * a.M) | 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), lds, s, a.P, a.sh_degree, a.M, a.means3D,
                        a.scales, a.scale_modifier, a.rotations, a.shs, a.cov3D_precomp, a.viewmatrix, a.projmatrix,
                        a.campos, a.W, a.H, a.tanfovx, a.tanfovy, fx, fy, radii, clamped,
                        reinterpret_cast<const float4*>(sums), g.dL_dmeans3D, g.dL_dmeans2D,

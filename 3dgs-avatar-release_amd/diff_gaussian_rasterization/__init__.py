@@ -166,7 +166,7 @@ _TILE_RECT = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
 # to 2048 tiles; on larger ones "auto" turns it on when the PREVIOUS frame of the same shape had such tiles (the forward
 # reports them in a pinned word), "1" / "0" force it on / off.  Outputs of the two settings agree to fp32 rounding.
 _LONG_LISTS = os.environ.get("GSPLAT_LONG_LISTS", "auto")
-_frame_stats = {}  # (device index, P, W, H) -> pinned int64[2]: [tiles with a long list, longest list] of the last frame
+_frame_stats = {}  # (device index, W, H) -> pinned int64[2]: [tiles with a long list, longest list] of the last frame
 
 
 def _stats_words(key):
@@ -202,7 +202,7 @@ def _make_args(settings, means3D, sh, colors_precomp, opacities, scales, rotatio
     a.prefiltered = int(bool(settings.prefiltered))
     a.debug = int(bool(settings.debug))
     a.tile_rect = _TILE_RECT
-    st = _stats_words((dev.index, P, a.W, a.H))
+    st = _stats_words((dev.index, a.W, a.H))  # (not keyed by P: densification changes it every few hundred steps)
     if long_lists is None:  # a forward: decided from the previous frame of this shape (stale or missing words: a guess as good)
         long_lists = 1 if (_LONG_LISTS == "1" or (_LONG_LISTS == "auto" and int(st[0]) > 0)) else 0
         a.frame_stats = st.data_ptr()
@@ -327,6 +327,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rc = L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
                                          img.data_ptr(), img_bytes, capacity, color.data_ptr(), sptr)
             _lib.check(rc)
+            if len(_last_count) > 256:  # (P changes with every densification: keep the table small)
+                _last_count.clear()
             _last_count[(dev.index, P, W, H)] = num_rendered
             if share:
                 # offered to the next call; owned by this call's autograd node (ctx), not by the cache

@@ -394,7 +394,7 @@ def test_long_lists_on_a_large_image_follow_the_previous_frames_statistics(oracl
     gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9))
     want = oracle.backward(sc, fw, gimg.numpy())
     monkeypatch.setattr(dgr, "_LONG_LISTS", "auto")
-    dgr._frame_stats.pop((0, n, W, H), None)
+    dgr._frame_stats.pop((0, W, H), None)
 
     def frame():
         kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
@@ -410,7 +410,7 @@ def test_long_lists_on_a_large_image_follow_the_previous_frames_statistics(oracl
         return mode, {k: v.cpu().numpy() for k, v in out.items()}
 
     m0, a = frame()
-    st = dgr._frame_stats[(0, n, W, H)]
+    st = dgr._frame_stats[(0, W, H)]
     assert m0 == 0 and int(st[0]) > 0 and int(st[1]) > 1000  # long lists seen and reported
     m1, b = frame()
     assert m1 == 1

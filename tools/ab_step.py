@@ -24,6 +24,7 @@ ap.add_argument("switch")
 ap.add_argument("--workload", default="config3")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=150)
+ap.add_argument("--also", default="", help="library switches held fixed for the whole run, e.g. fwd4=0,xcd_map=1")
 args = ap.parse_args()
 target, values = args.switch.split("=")
 if target.startswith("lib:"):  # a gs_tuning switch of the library, e.g. lib:xcd_map=1,0
@@ -40,6 +41,11 @@ else:
     def apply(v):
         setattr(mod, attr, v)
 
+if args.also:
+    from gsplat_mi355 import _lib as _l
+    for kv in args.also.split(","):
+        k, v = kv.split("=")
+        _l.tuning(k, int(v))
 N, W, H, deg, tail, do_bwd = bench.WORKLOADS[args.workload]
 dev = torch.device("cuda:0")
 cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev, layout=bench.WORKLOAD_LAYOUT.get(args.workload, "box"))
