@@ -82,13 +82,16 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     bool live = __ballot(T > 0.f) != 0ull;  // wave-uniform
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-    uint32_t pid_g = 0;
+    // Prefetch two deep: the list index of the batch after next, the record of the next batch -- a record load depends
+    // on its index load, and the two in a row (two trips to the L2 or beyond) are longer than a batch of few hits takes
+    uint32_t pid_g = 0, pid_n = 0;
     if (live && lane < n) {
         pid_g = point_list[range.x + lane];
         p0 = rec[(size_t)pid_g * 3];
         p1 = rec[(size_t)pid_g * 3 + 1];
         p2 = rec[(size_t)pid_g * 3 + 2];
     }
+    if (live && 64 + lane < n) pid_n = point_list[range.x + 64 + lane];
     for (int base = 0; base < n && live; base += 64) {
         Staged s;
         const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + lane < n);
@@ -107,10 +110,11 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         wave_lds_sync();
         kcount += (uint32_t)cnt;
         if (base + 64 + lane < n) {
-            pid_g = point_list[range.x + base + 64 + lane];
+            pid_g = pid_n;
             p0 = rec[(size_t)pid_g * 3];
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
+            if (base + 128 + lane < n) pid_n = point_list[range.x + base + 128 + lane];
         }
         // The staged entries are read at a wave-uniform address.  Keeping that address in a VGPR the
         // compiler cannot prove uniform (vzero) makes it one v_add per entry + immediate offsets; proven
@@ -273,13 +277,14 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     bool live = QX0 < W && QY0 < H;  // (workgroup-uniform) the quadrant has a pixel inside the image
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-    uint32_t pid_g = 0;
+    uint32_t pid_g = 0, pid_n = 0;  // (two deep, as in render_quadrant_1)
     if (live && tid < n) {
         pid_g = point_list[range.x + tid];
         p0 = rec[(size_t)pid_g * 3];
         p1 = rec[(size_t)pid_g * 3 + 1];
         p2 = rec[(size_t)pid_g * 3 + 2];
     }
+    if (live && FWD4_BATCH + tid < n) pid_n = point_list[range.x + FWD4_BATCH + tid];
     for (int base = 0; base < n && live; base += FWD4_BATCH) {
         Staged s;
         const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + tid < n);
@@ -307,10 +312,11 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         const uint32_t kbase = kcount;  // compacted index of this batch's first entry
         kcount += (uint32_t)cnt;
         if (base + FWD4_BATCH + tid < n) {
-            pid_g = point_list[range.x + base + FWD4_BATCH + tid];
+            pid_g = pid_n;
             p0 = rec[(size_t)pid_g * 3];
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
+            if (base + 2 * FWD4_BATCH + tid < n) pid_n = point_list[range.x + base + 2 * FWD4_BATCH + tid];
         }
         // a chunk of the backward starts where the previous one has its BWD_CH entries (common.h, BWD_CH): at a step
         // boundary, here also in the middle of a batch (a batch holds up to 256 entries)
