@@ -332,13 +332,8 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         };
         const char* sp = reinterpret_cast<const char*>(srec) + e * 48;
         uint32_t idx1 = kbase + (uint32_t)e + 1u;  // compacted index of this lane's entry, 1-based
-        for (int j = 0; j < cnt; j += 4) {
-            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);  // (workgroup-uniform)
-            const float4 a = *reinterpret_cast<const float4*>(sp);
-            const float2 b = *reinterpret_cast<const float2*>(sp + 16);
-            const float4 c = *reinterpret_cast<const float4*>(sp + 32);
-            asm volatile("" ::"v"(c.w));  // one ds_read_b128 (render_fwd_kernel)
-            sp += 4 * 48;
+        // one step: the four entries a / b / c hold (one per lane of the quad) against the wave's 16 pixels
+        auto step = [&](const float4 a, const float2 b, const float4 c) {
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
@@ -370,6 +365,32 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             mag = min(mag, qperm<QP_X1>(mag));
             mag = min(mag, qperm<QP_X2>(mag));
             T = __uint_as_float(mag | (~qperm<QP_LAST>(ok) & 0x80000000u));
+        };
+        auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
+        auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
+        auto ld_c = [&](int o) {
+            const float4 c = *reinterpret_cast<const float4*>(sp + o + 32);
+            asm volatile("" ::"v"(c.w));  // one ds_read_b128 (render_quadrant_1)
+            return c;
+        };
+        // two steps per trip over two register sets: the next step's LDS reads are issued before the current one is
+        // evaluated (reads up to one step past the padded batch: srec has the room; what is read there is never used)
+        float4 a0 = ld_a(0), c0 = ld_c(0);
+        float2 b0 = ld_b(0);
+        int j = 0;
+        for (; j + 4 < cnt; j += 8) {
+            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);  // (workgroup-uniform)
+            const float4 a1 = ld_a(192), c1 = ld_c(192);
+            const float2 b1 = ld_b(192);
+            step(a0, b0, c0);
+            if (nck + 1 < chunks && kbase + (uint32_t)j + 4u >= next_ck) checkpoint(kbase + (uint32_t)j + 4u);
+            a0 = ld_a(384); c0 = ld_c(384); b0 = ld_b(384);
+            sp += 384;
+            step(a1, b1, c1);
+        }
+        if (j < cnt) {
+            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);
+            step(a0, b0, c0);
         }
         {
             uint32_t lk = max(last_k, qperm<QP_X1>(last_k));

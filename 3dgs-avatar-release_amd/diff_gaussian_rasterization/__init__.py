@@ -85,12 +85,13 @@ class _GeomCache(object):
             return None
         return (id(t), t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
-    def key(self, settings, means3D, opacities, scales, rotations, cov3D):
+    def key(self, settings, means3D, opacities, scales, rotations, cov3D, stream_handle=None):
         tensors = (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix, settings.projmatrix, settings.campos)
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
                              float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT,
                              # the cached state is only valid in stream order: a hit must come from the same stream
-                             int(torch.cuda.current_stream(means3D.device).cuda_stream)),
+                             int(torch.cuda.current_stream(means3D.device).cuda_stream) if stream_handle is None
+                             else int(stream_handle)),
                     sigs=[self._sig(t) for t in tensors],
                     # the objects themselves: an id() can only be trusted while its object is alive
                     objs=[t for t in tensors if t is not None and t.numel() > 0])
@@ -120,6 +121,19 @@ def release_shared_geometry():
     """Withdraws any geometry state on offer to a following call (it is otherwise withdrawn by the next forward, by the
     producing call's backward, or when its autograd graph is freed)."""
     _geom_cache.clear()
+
+
+_sizes = {}  # memo of the library's size queries (pure functions of their arguments)
+
+
+def _size(fn_name, *args):
+    k = (fn_name,) + args
+    v = _sizes.get(k)
+    if v is None:
+        if len(_sizes) > 4096:
+            _sizes.clear()
+        v = _sizes[k] = _lib.nbytes(getattr(_lib.load(), fn_name), *args)
+    return v
 
 
 _last_count = {}  # (device, P, W, H) -> num_rendered of the previous call: a sizing hint only
@@ -273,14 +287,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                            keep)
             stream = torch.cuda.current_stream(dev)
             sptr = ctypes.c_void_p(stream.cuda_stream)
-            geom_bytes = _lib.nbytes(L.gs_geom_bytes, P)
-            img_bytes = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
+            geom_bytes = _size("gs_geom_bytes", P)
+            ik = ("img", W, H, int(a.long_lists))
+            img_bytes = _sizes.get(ik)
+            if img_bytes is None:
+                img_bytes = _sizes[ik] = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
             geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
             img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             share = _SHARE and any(ctx.needs_input_grad)  # (true only under grad mode)
-            gkey = _geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp) if share else None
+            gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream.cuda_stream)
+                    if share else None)
             hit = _geom_cache.take(dev, gkey) if share else None
             if not share:
                 _geom_cache.offer.pop(dev.index, None)
@@ -303,7 +321,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        "state it shares with the previous call")
                 return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
-                                                   img, color, dev, a, sptr)
+                                                   img, color, dev, a, sptr, keep)
             count = _pinned_count(dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
@@ -313,7 +331,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # does control come back here to allocate and run phase 2 again.
             guess = _last_count.get((dev.index, P, W, H), 0)
             capacity = _capacity_for(guess) if (guess and _SPECULATE) else 0
-            bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H) if capacity else 0
+            bin_bytes = _size("gs_binning_bytes", capacity, W, H) if capacity else 0
             binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev) if capacity else None
             nr = ctypes.c_int64(0)
             rc = L.gs_forward(ctypes.byref(a), geom.data_ptr(), geom_bytes, _lib.ptr(binning), bin_bytes, capacity,
@@ -322,7 +340,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered = int(nr.value)
             if rc == _lib.GS_E_WORKSPACE:
                 capacity = num_rendered
-                bin_bytes = _lib.nbytes(L.gs_binning_bytes, capacity, W, H)
+                bin_bytes = _size("gs_binning_bytes", capacity, W, H)
                 binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
                 rc = L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
                                          img.data_ptr(), img_bytes, capacity, color.data_ptr(), sptr)
@@ -336,11 +354,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _geom_cache.put(dev, ctx.geom_entry)
             return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color,
-                                               dev, a, sptr)
+                                               dev, a, sptr, keep)
 
     @staticmethod
     def _finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr):
+                cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr, keep=None):
         opacity = None
         if ctx.with_opacity:
             # the opacity render is (1 - final_T) + final_T * bg[0]: the forward that just ran holds final_T
@@ -350,6 +368,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(L.gs_opacity_image(ctypes.byref(a), img.data_ptr(), img.numel(), opacity.data_ptr(), sptr))
         ctx.raster_settings = raster_settings
         ctx.long_lists = int(a.long_lists)  # the backward must be told the same (GsFwdArgs.long_lists)
+        ctx.fwd_args = (a, keep)  # the argument block (pointers into the saved tensors) serves the backward as it is
         ctx.num_rendered = num_rendered  # the frame's pair count (upstream's num_rendered)
         ctx.capacity = capacity          # pairs the binning state is carved for (>= num_rendered): what the backward is given
         ctx.present = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -391,13 +410,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         g = _f32c(grad_out_color, "grad_out_color")
         g_op = _f32c(grad_out_opacity, "grad_out_opacity") if (ctx.with_opacity and grad_out_opacity is not None) else None
-        keep = []
         with torch.cuda.device(dev):
-            a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
-                           scales if has_sr else None, rotations if has_sr else None,
-                           cov3Ds_precomp if has_cov else None, keep, long_lists=ctx.long_lists)
+            a, _keep = ctx.fwd_args  # the forward's argument block: the same tensors (saved above), the same long_lists
             sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            scratch_bytes = _lib.nbytes(L.gs_backward_scratch_bytes, D, P, W, H)
+            scratch_bytes = _size("gs_backward_scratch_bytes", D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
             M = int(sh.shape[1]) if has_sh else 0
             f = dict(dtype=torch.float32, device=dev)
