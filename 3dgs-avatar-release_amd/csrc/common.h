@@ -135,7 +135,9 @@ int gs_tune_get(int key);
 #define BWD_CHUNK_MAX_TILES 2048
 #define FWD4_MAX_TILES 2048   // the forward runs four waves per quadrant up to this many tiles (render_fwd.hip)
 #define FWD4_MIN_LIST 512u    // ... all four on the tiles whose list is longer than this and than (frame's pairs) / FWD4_TOTAL_DIV
-#define FWD4_TOTAL_DIV 320ull
+#ifndef FWD4_TOTAL_DIV
+#define FWD4_TOTAL_DIV 320ull  // (160: avatar frame - 1.5 %; 640: configs 2 and 4 - 13 % / - 5 %; 1280: - 18 % / - 9 %)
+#endif
 
 struct ImgLayout {
     size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, ck_start, total;
