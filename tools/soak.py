@@ -10,7 +10,8 @@ from gsplat_mi355.scenes import GaussianCloud, synthetic_cloud
 
 dev = torch.device("cuda:0")
 N, W, H, STEPS = 100000, 512, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-cloud = synthetic_cloud(N, sh_degree=3, seed=3, device=dev)
+LAYOUT = sys.argv[2] if len(sys.argv) > 2 else "box"  # "body": a thin-shell cloud (long tile lists: four-wave forward, chunked backward)
+cloud = synthetic_cloud(N, sh_degree=3, seed=3, device=dev, layout=LAYOUT)
 for f in GaussianCloud.FIELDS:
     getattr(cloud, f).requires_grad_(True)
 lrs = dict(xyz=1e-6, scales=1e-6, rotations=1e-5, opacity=1e-4, shs=1e-3)
