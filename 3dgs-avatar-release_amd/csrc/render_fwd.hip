@@ -131,7 +131,10 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             next_ck = kbase + BWD_CH;
         }
         // One entry against the 64 pixels.  `a`, `b`, `c` = the three staged quads of the entry.
-        auto blend = [&](const float4 a, const float2 b, const float4 c, const uint32_t k1) {
+        // `mark`: set to the loop's LDS address register where the pair is blended -- the entry's index in the batch is
+        // read back from it after the loop (a select between two VGPRs; selecting the wave-uniform index itself costs a
+        // v_mov per entry on top, an SGPR cannot be the second source next to vcc)
+        auto blend = [&](const float4 a, const float2 b, const float4 c, uint32_t& mark) {
             const float dx = a.x - pxf, dy = a.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2, evaluated exactly as the backward does
             const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
@@ -146,7 +149,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
-            last_k = (w > 0.f) ? k1 : last_k;  // (a wave-uniform value: no LDS operand)
+            mark = (w > 0.f) ? (uint32_t)(uintptr_t)sp : mark;
         };
         // The loop is software-pipelined by hand, two entries per trip: the LDS reads of the NEXT entry are issued
         // before the current one is evaluated.  With eight waves per SIMD the LDS latency hides behind the other waves
@@ -164,16 +167,26 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         };
         float4 a0 = ld_a(0), c0 = ld_c(0);
         float2 b0 = ld_b(0);
+        // even entries of the batch are evaluated with sp at their own address, odd ones with sp 48 bytes past theirs
+        const uint32_t sp0 = (uint32_t)(uintptr_t)sp;
+        uint32_t mark_e = 0xFFFFFFFFu, mark_o = 0xFFFFFFFFu;  // (no LDS address)
         int j = 0;
         for (; j + 1 < cnt; j += 2) {
             const float4 a1 = ld_a(48), c1 = ld_c(48);
             const float2 b1 = ld_b(48);
-            blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
+            blend(a0, b0, c0, mark_e);
             a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
             sp += 96;
-            blend(a1, b1, c1, kbase + (uint32_t)j + 2u);
+            blend(a1, b1, c1, mark_o);
         }
-        if (j < cnt) blend(a0, b0, c0, kbase + (uint32_t)j + 1u);
+        if (j < cnt) blend(a0, b0, c0, mark_e);
+        {
+            // the last blended entry of the batch, as a 1-based compacted index (48-byte entries: x / 48 = x * 43691 >> 21
+            // for x < 2^15)
+            const uint32_t ke = mark_e != 0xFFFFFFFFu ? kbase + (((mark_e - sp0) * 43691u) >> 21) + 1u : 0u;
+            const uint32_t ko = mark_o != 0xFFFFFFFFu ? kbase + (((mark_o - sp0) * 43691u) >> 21) : 0u;
+            last_k = max(last_k, max(ke, ko));
+        }
         // the last contributor's position in the TILE's list (n_contrib), looked up once per batch
         if (last_k > kbase) last = __float_as_uint(srec[(last_k - 1u - kbase) * 3 + 2].w);
         live = __ballot(T > 0.f) != 0ull;  // every pixel of the quadrant frozen: stop
