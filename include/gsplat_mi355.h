@@ -280,9 +280,12 @@ int gs_profile_enable(int on);
 int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
 int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
 
-/* process-wide tuning switch for experiments and A/B measurements; no effect on results.  "xcd_map" (1: the four
- * quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's
- * row-mark fill is written with streaming stores) */
+/* process-wide tuning switches for experiments and A/B measurements.  Without effect on the results: "xcd_map" (1: the
+ * four quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's
+ * row-mark fill is written with streaming stores).  With an effect of fp32 rounding (which kernels render a frame of few,
+ * long tile lists; flip them between frames only, "small_tiles" also changes the image state's size): "fwd4" (1: four
+ * waves per quadrant, four entries per step on the marked tiles), "bwd_chunks" (1: backward in chunks from the forward's
+ * checkpoints), "small_tiles" (images of up to this many tiles use both whatever GsFwdArgs.long_lists says; 2048) */
 int gs_tuning(const char* name, int value);
 const char* gs_status_string(int code);
 int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */
