@@ -412,6 +412,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_op = _f32c(grad_out_opacity, "grad_out_opacity") if (ctx.with_opacity and grad_out_opacity is not None) else None
         with torch.cuda.device(dev):
             a, _keep = ctx.fwd_args  # the forward's argument block: the same tensors (saved above), the same long_lists
+            if (a.means3D != means3D.data_ptr() or a.opacities != opacities.data_ptr()
+                    or (has_sh and a.shs != sh.data_ptr()) or (has_sr and a.scales != scales.data_ptr())):
+                # the saved tensors came back in other storage (saved-tensor hooks: offloading, checkpointing)
+                _keep = []
+                a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
+                               scales if has_sr else None, rotations if has_sr else None,
+                               cov3Ds_precomp if has_cov else None, _keep, long_lists=ctx.long_lists)
             sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             scratch_bytes = _size("gs_backward_scratch_bytes", D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)

@@ -1223,6 +1223,36 @@ def test_random_small_scenes_against_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_backward_with_saved_tensors_relocated_by_hooks():
+    """torch.autograd.graph.save_on_cpu moves every saved tensor to the host and back into NEW device storage for the
+    backward: the wrapper must not use the device addresses it took in the forward (its argument block is rebuilt when
+    the saved tensors have moved).  Same gradients, bit for bit, as without the hook."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 4000, 96, 80
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=12, scale_mul=1.5)
+    bg = (0.1, 0.1, 0.1)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(offload):
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        rast = GaussianRasterizer(_settings(cam, cloud, bg, dev))
+        if offload:
+            with torch.autograd.graph.save_on_cpu():
+                color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        else:
+            color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        (color * gimg).sum().backward()
+        return [t.grad.clone() for t in (means3D, means2D, opac, kw["shs"], kw["scales"], kw["rotations"])]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_random_dense_small_scenes_against_oracle(oracle):
     """Fuzz of the few-long-lists paths (four-wave forward on marked tiles, backward in chunks): ten random DENSE small
     scenes -- thousands of entries per tile on ragged images of a few dozen tiles, thin-shell and box clouds, opaque to
