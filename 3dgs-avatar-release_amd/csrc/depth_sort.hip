@@ -102,7 +102,7 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
             pn.count[0] = total;
             // ... and straight into the caller's pinned host word, which the host is polling: the pair count
             // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
-            if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the host reads this word only: no release -- a system-scope release writes the L2 back)
         }
     }
     uint32_t k[DS_ITEMS / DS_THREADS];
