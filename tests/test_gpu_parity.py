@@ -598,7 +598,8 @@ def _sorted_list_properties(st):
     assert (st["image"]["final_T"] <= 1).all() and (st["image"]["final_T"] > 0).all()
 
 
-def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_pairs=0, extra_properties=False):
+def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_pairs=0, extra_properties=False,
+                    layout="box"):
     """One BASELINE configuration at FULL size through the HIP path against the oracle in the same binning mode:
     integers (radii, tiles_touched, num_rendered, the sorted (tile, depth) list, the tile ranges) bit-exact; image,
     final_T and all six gradient tensors inside the float bar with bounded outliers; errors recorded in the parity
@@ -607,7 +608,7 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
     from gsplat_mi355 import debug
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda:0")
-    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=frame, heavy_tail=heavy_tail,
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=frame, heavy_tail=heavy_tail, layout=layout,
                                           dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
     bg = (0.0, 0.0, 0.0)
     sc = helpers.oracle_scene(cloud, cam, bg=bg, tile_rect=tile_rect)
@@ -699,6 +700,15 @@ def test_full_size_config5_500k_2048_heavy_tail(oracle, tile_rect):
     point list, tile ids and ranges bit-exact, image and gradients inside the float bar, list properties."""
     _full_size_case(oracle, "config5 500k/2048x2048 heavy tail", 500000, 2048, 2048, 0.05, tile_rect,
                     min_pairs=35000000 if tile_rect == 0 else 20000000)
+
+
+def test_full_size_trained_avatar_shaped_frame_200k_512(oracle, tile_rect):
+    """Not a BASELINE configuration: the shape of a TRAINED avatar at full size (bench.py --workload avatar: 200k
+    Gaussians on a thin shell covering a sixth of 512 x 512, mostly opaque -- 150 tiles with lists of 2000-7000 entries),
+    the frame the four-wave forward and the chunked backward exist for, through the same checks as the configurations:
+    lists and ranges bit-exact, image and gradients inside the float bar, bitwise repeatable, linear."""
+    _full_size_case(oracle, "avatar 200k/512x512", 200000, 512, 512, 0.0, tile_rect, min_pairs=300000,
+                    extra_properties=True, layout="body")
 
 
 def test_heavy_tail_stress_config5_shape(oracle):
