@@ -64,6 +64,13 @@ __device__ __forceinline__ bool stage_entry_quad(const float4 r0, const float4 r
     return hit;
 }
 
+// the staged form alone (no footprint test): for a walk of a quadrant's recorded compacted list, whose entries are hits
+__device__ __forceinline__ void stage_entry_convert(const float4 r0, const float4 r1, const float4 r2, Staged& s) {
+    s.a = make_float4(r0.x, r0.y, (-0.5f * LOG2E_F) * r0.z, -LOG2E_F * r0.w);
+    s.b = make_float4((-0.5f * LOG2E_F) * r1.x, r1.y, 0.f, 0.f);
+    s.c = make_float4(r1.z, r1.w, r2.x, 0.f);
+}
+
 // ---- DPP helpers (cross-lane moves without LDS) ----
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_get(float v) {

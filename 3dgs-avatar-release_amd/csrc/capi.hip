@@ -21,6 +21,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_NT_STORES].store(1);
     g_tune[GS_TUNE_BWD_CHUNKS].store(1);
     g_tune[GS_TUNE_FWD4].store(1);
+    g_tune[GS_TUNE_SHARED_QLIST].store(1);
     g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
 }
 int gs_tune_get(int key) {
@@ -332,9 +333,13 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     if (e != hipSuccess) { gs_set_error((int)e, "shared.copy"); return GS_E_HIP; }
     const uint32_t* point_list = D > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
     QuadLists ql;
-    ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // rewritten with identical content (same geometry)
+    ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // read, not rewritten: the recorded quadrant lists are what is walked
     ql.ncon_c = (uint32_t*)(im + I.ncon_c);
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
+    if (gs_tune_get(GS_TUNE_SHARED_QLIST)) {
+        ql.src_qcount = (const uint32_t*)(is + I.tile_nmax);  // (the fields before the checkpoints sit at the same offsets
+        ql.src_n_contrib = (const uint32_t*)(is + I.n_contrib);  //  whatever long_lists the first render was given)
+    }
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
@@ -648,6 +653,7 @@ int gs_tuning(const char* name, int value) {
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
     if (strcmp(name, "small_tiles") == 0) { g_tune[GS_TUNE_SMALL_TILES].store(value); return GS_OK; }  // changes the image state's size
+    if (strcmp(name, "shared_qlist") == 0) { g_tune[GS_TUNE_SHARED_QLIST].store(value); return GS_OK; }
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }

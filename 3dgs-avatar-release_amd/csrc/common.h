@@ -121,7 +121,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 // process-wide tuning switches (gs_tuning)
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_COUNT = 8 };
 int gs_tune_get(int key);
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
@@ -330,6 +330,9 @@ struct QuadLists {
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
     int four_waves = 0;      // forward: four waves per quadrant, all used on the tiles marked in the launch order
+    // forward of a second render of the same geometry: the first render's per-quadrant counts and n_contrib (or null)
+    const uint32_t* src_qcount = nullptr;
+    const uint32_t* src_n_contrib = nullptr;
     float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
     uint32_t* ck_start = nullptr;  // [quadrant][chunks]: compacted index every chunk starts at
     int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)

@@ -33,6 +33,10 @@ struct FwdArgs {
     float4* __restrict__ ckpt;
     uint32_t* __restrict__ ck_start;
     int chunks;
+    // a second render of the same geometry (gs_forward_shared): the first render's per-quadrant counts and n_contrib --
+    // the quadrants' recorded compacted lists (qlist) are walked instead of the tiles' lists
+    const uint32_t* __restrict__ src_qcount;
+    const uint32_t* __restrict__ src_n_contrib;
 };
 
 // between two phases of ONE wave that exchange data through LDS (a wave's LDS operations execute in order)
@@ -43,6 +47,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // One wave, one quadrant (tile, q), one entry per step.  `srec`: LDS for 66 staged entries (64 + the two the pipelined
 // loop may read past a batch).
+template <bool FQ>
 __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int tile, const int q, float4* __restrict__ srec) {
     const float4* __restrict__ rec = A.rec;
     const uint32_t* __restrict__ point_list = A.point_list;
@@ -63,8 +68,12 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = px < W && py < H;
     const uint2 range = A.ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;  // this quadrant's slice of qlist / gradient rows
+    const int n_tile = (int)(range.y - range.x);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n_tile;  // this quadrant's slice of qlist / gradient rows
+    // what is walked: the tile's list, or (FQ) the quadrant's own compacted list as the first render recorded it -- up to
+    // its last contributor: the colours do not change which entries contribute
+    const int n = FQ ? (int)A.src_qcount[tile * 4 + q] : n_tile;
+    const uint32_t* __restrict__ list = FQ ? qlist + qbase : point_list + range.x;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -78,7 +87,6 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;  // wave-uniform: compacted entries staged so far
     int nck = 0;                   // checkpoints written so far (chunks of the backward begun, less one)
-    uint32_t next_ck = BWD_CH;     // ... the next one is due at the first batch that starts at or beyond this entry
     bool live = __ballot(T > 0.f) != 0ull;  // wave-uniform
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
@@ -86,15 +94,21 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     // on its index load, and the two in a row (two trips to the L2 or beyond) are longer than a batch of few hits takes
     uint32_t pid_g = 0, pid_n = 0;
     if (live && lane < n) {
-        pid_g = point_list[range.x + lane];
+        pid_g = list[lane];
         p0 = rec[(size_t)pid_g * 3];
         p1 = rec[(size_t)pid_g * 3 + 1];
         p2 = rec[(size_t)pid_g * 3 + 2];
     }
-    if (live && 64 + lane < n) pid_n = point_list[range.x + 64 + lane];
+    if (live && 64 + lane < n) pid_n = list[64 + lane];
     for (int base = 0; base < n && live; base += 64) {
         Staged s;
-        const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + lane < n);
+        bool hit;
+        if (FQ) {
+            stage_entry_convert(p0, p1, p2, s);
+            hit = base + lane < n;
+        } else {
+            hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + lane < n);
+        }
         const unsigned long long bal = __ballot(hit);
         const int cnt = __popcll(bal);
         wave_lds_sync();
@@ -105,7 +119,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             srec[slot * 3] = s.a;
             srec[slot * 3 + 1] = s.b;
             srec[slot * 3 + 2] = s.c;
-            qlist[qbase + k] = pid_g;  // record the compaction for the backward
+            if (!FQ) qlist[qbase + k] = pid_g;  // record the compaction for the backward
         }
         wave_lds_sync();
         kcount += (uint32_t)cnt;
@@ -114,7 +128,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             p0 = rec[(size_t)pid_g * 3];
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
-            if (base + 128 + lane < n) pid_n = point_list[range.x + base + 128 + lane];
+            if (base + 128 + lane < n) pid_n = list[base + 128 + lane];
         }
         // The staged entries are read at a wave-uniform address.  Keeping that address in a VGPR the
         // compiler cannot prove uniform (vzero) makes it one v_add per entry + immediate offsets; proven
@@ -122,14 +136,6 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         // the CU's single scalar unit becomes the bottleneck.
         const char* sp = reinterpret_cast<const char*>(srec) + vzero;
         const uint32_t kbase = kcount - (uint32_t)cnt;  // compacted index of this batch's first entry
-        // a chunk of the backward starts here when the previous one has its BWD_CH entries (common.h, BWD_CH): the state
-        // before this batch is checkpointed
-        if (nck + 1 < chunks && kbase >= next_ck) {
-            ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)nck) * 64 + lane] = make_float4(fabsf(T), C0, C1, C2);
-            nck++;
-            if (lane == 0) ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + nck] = kbase;
-            next_ck = kbase + BWD_CH;
-        }
         // One entry against the 64 pixels.  `a`, `b`, `c` = the three staged quads of the entry.
         // `mark`: set to the loop's LDS address register where the pair is blended -- the entry's index in the batch is
         // read back from it after the loop (a select between two VGPRs; selecting the wave-uniform index itself costs a
@@ -165,21 +171,43 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             asm volatile("" ::"v"(c.w));
             return c;
         };
-        float4 a0 = ld_a(0), c0 = ld_c(0);
-        float2 b0 = ld_b(0);
-        // even entries of the batch are evaluated with sp at their own address, odd ones with sp 48 bytes past theirs
+        // even entries of a run are evaluated with sp at their own address, odd ones with sp 48 bytes past theirs
         const uint32_t sp0 = (uint32_t)(uintptr_t)sp;
         uint32_t mark_e = 0xFFFFFFFFu, mark_o = 0xFFFFFFFFu;  // (no LDS address)
-        int j = 0;
-        for (; j + 1 < cnt; j += 2) {
-            const float4 a1 = ld_a(48), c1 = ld_c(48);
-            const float2 b1 = ld_b(48);
-            blend(a0, b0, c0, mark_e);
-            a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
-            sp += 96;
-            blend(a1, b1, c1, mark_o);
+        // entries [j0, j1) of the batch (sp stands at entry j0, and at entry j1 afterwards)
+        auto run = [&](const int j0, const int j1) {
+            float4 a0 = ld_a(0), c0 = ld_c(0);
+            float2 b0 = ld_b(0);
+            int j = j0;
+            for (; j + 1 < j1; j += 2) {
+                const float4 a1 = ld_a(48), c1 = ld_c(48);
+                const float2 b1 = ld_b(48);
+                blend(a0, b0, c0, mark_e);
+                a0 = ld_a(96); c0 = ld_c(96); b0 = ld_b(96);
+                sp += 96;
+                blend(a1, b1, c1, mark_o);
+            }
+            if (j < j1) {
+                blend(a0, b0, c0, mark_e);
+                sp += 48;
+            }
+        };
+        // A chunk of the backward starts at every compacted index c BWD_CH, 0 < c < chunks (common.h, BWD_CH) -- at the
+        // index itself, wherever it falls in a batch, so that the chunks do not depend on how the list is cut into
+        // batches (the tile's list, or the recorded quadrant list for a second render of the same geometry: the same
+        // gradient bits).  At most one such index per batch (64 <= BWD_CH): the batch runs in two parts around it.
+        int jc = cnt;
+        if (chunks > 1) {
+            const uint32_t r = (BWD_CH - (kbase & (BWD_CH - 1u))) & (BWD_CH - 1u);
+            if (r < (uint32_t)cnt && kbase + r > 0u && kbase + r < (uint32_t)chunks * BWD_CH) jc = (int)r;
         }
-        if (j < cnt) blend(a0, b0, c0, mark_e);
+        run(0, jc);
+        if (jc < cnt) {
+            nck = (int)((kbase + (uint32_t)jc) / BWD_CH);  // (this is checkpoint nck - 1: they come in order)
+            ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)(nck - 1)) * 64 + lane] = make_float4(fabsf(T), C0, C1, C2);
+            if (lane == 0) ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + nck] = kbase + (uint32_t)jc;
+            run(jc, cnt);
+        }
         {
             // the last blended entry of the batch, as a 1-based compacted index (48-byte entries: x / 48 = x * 43691 >> 21
             // for x < 2^15)
@@ -202,7 +230,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         const size_t pid = (size_t)py * W + px;
         const float Tf = fabsf(T);
         final_T[pid] = Tf;
-        n_contrib[pid] = last;
+        n_contrib[pid] = FQ ? A.src_n_contrib[pid] : last;
         ncon_c[pid] = last_k;
         out_color[pid] = C0 + Tf * bg[0];
         out_color[HW + pid] = C1 + Tf * bg[1];
@@ -210,12 +238,13 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     }
 }
 
+template <bool FQ>
 __global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
     __shared__ float4 srec[66 * 3];
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot >= A.ntiles) return;
-    render_quadrant_1(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
+    render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -248,8 +277,9 @@ __device__ __forceinline__ uint32_t qperm(uint32_t v) {
 #define QP_LAST 0xFF   // quad_perm [3,3,3,3]
 #define FWD4_BATCH 256
 
-// Four waves, one quadrant (tile, q), four entries per step.  `srec`: LDS for FWD4_BATCH + 8 staged entries (a batch's
+// Four waves, one quadrant (tile, q), four entries per step.  `srec`: LDS for FWD4_BATCH + 12 staged entries (a batch's
 // compacted entries and four all-zero ones behind them); s_cnt / s_flag / s_lastk: four words each.
+template <bool FQ>
 __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int tile, const int q, float4* __restrict__ srec,
                                                   uint32_t* __restrict__ s_cnt, uint32_t* __restrict__ s_flag,
                                                   uint32_t* __restrict__ s_lastk) {
@@ -276,8 +306,10 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     const bool inside = px < W && py < H;
     const int pix_q = 16 * wv + p;  // the pixel's index in the quadrant, (py - QY0) * 8 + (px - QX0)
     const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n;
+    const int n_tile = (int)(range.y - range.x);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n_tile;
+    const int n = FQ ? (int)A.src_qcount[tile * 4 + q] : n_tile;  // (render_quadrant_1)
+    const uint32_t* __restrict__ list = FQ ? qlist + qbase : point_list + range.x;
     const size_t quad = (size_t)(tile * 4 + q);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -286,40 +318,53 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;
     int nck = 0;
-    uint32_t next_ck = BWD_CH;
     bool live = QX0 < W && QY0 < H;  // (workgroup-uniform) the quadrant has a pixel inside the image
 
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     uint32_t pid_g = 0, pid_n = 0;  // (two deep, as in render_quadrant_1)
     if (live && tid < n) {
-        pid_g = point_list[range.x + tid];
+        pid_g = list[tid];
         p0 = rec[(size_t)pid_g * 3];
         p1 = rec[(size_t)pid_g * 3 + 1];
         p2 = rec[(size_t)pid_g * 3 + 2];
     }
-    if (live && FWD4_BATCH + tid < n) pid_n = point_list[range.x + FWD4_BATCH + tid];
+    if (live && FWD4_BATCH + tid < n) pid_n = list[FWD4_BATCH + tid];
     for (int base = 0; base < n && live; base += FWD4_BATCH) {
         Staged s;
-        const bool hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + tid < n);
+        bool hit;
+        if (FQ) {
+            stage_entry_convert(p0, p1, p2, s);
+            hit = base + tid < n;
+        } else {
+            hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + tid < n);
+        }
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
         __syncthreads();  // (the previous batch's readers of srec are done, too)
         const uint32_t n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
         const int cnt = (int)(n0 + n1 + n2 + n3);
         const uint32_t woff = wv == 0 ? 0u : (wv == 1 ? n0 : (wv == 2 ? n0 + n1 : n0 + n1 + n2));
+        // Entry k of the quadrant's compacted list is always evaluated by lane k mod 4 of the quads, however the list is cut
+        // into batches: the per-lane colour sums are then the same whether the walk goes over the tile's list (256 list
+        // entries per batch) or over the recorded quadrant list (256 hits per batch: a second render of the same
+        // geometry) -- bit-identical images.  The batch is staged behind `lead` = kcount mod 4 all-zero entries.
+        const uint32_t lead = kcount & 3u;
         if (hit) {
             const uint32_t sl = woff + (uint32_t)__popcll(bal & lt_mask);
             s.c.w = __uint_as_float((uint32_t)(base + tid + 1));  // position in the tile's list (1-based)
-            srec[sl * 3] = s.a;
-            srec[sl * 3 + 1] = s.b;
-            srec[sl * 3 + 2] = s.c;
-            qlist[qbase + kcount + sl] = pid_g;  // record the compaction for the backward
+            srec[(lead + sl) * 3] = s.a;
+            srec[(lead + sl) * 3 + 1] = s.b;
+            srec[(lead + sl) * 3 + 2] = s.c;
+            if (!FQ) qlist[qbase + kcount + sl] = pid_g;  // record the compaction for the backward
         }
-        if (tid < 4) {  // entries of opacity 0 behind the batch: a step always evaluates four
+        if (tid < 7) {  // entries of opacity 0 before (lead) and behind the batch: a step always evaluates four
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            srec[(cnt + tid) * 3] = z;
-            srec[(cnt + tid) * 3 + 1] = z;
-            srec[(cnt + tid) * 3 + 2] = z;
+            const uint32_t zs = tid < 4 ? lead + (uint32_t)cnt + (uint32_t)tid : (uint32_t)tid - 4u;
+            if (tid < 4 || zs < lead) {
+                srec[zs * 3] = z;
+                srec[zs * 3 + 1] = z;
+                srec[zs * 3 + 2] = z;
+            }
         }
         __syncthreads();
         const uint32_t kbase = kcount;  // compacted index of this batch's first entry
@@ -329,22 +374,35 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             p0 = rec[(size_t)pid_g * 3];
             p1 = rec[(size_t)pid_g * 3 + 1];
             p2 = rec[(size_t)pid_g * 3 + 2];
-            if (base + 2 * FWD4_BATCH + tid < n) pid_n = point_list[range.x + base + 2 * FWD4_BATCH + tid];
+            if (base + 2 * FWD4_BATCH + tid < n) pid_n = list[base + 2 * FWD4_BATCH + tid];
         }
         // a chunk of the backward starts where the previous one has its BWD_CH entries (common.h, BWD_CH): at a step
         // boundary, here also in the middle of a batch (a batch holds up to 256 entries)
-        auto checkpoint = [&](const uint32_t k0) {
+        auto checkpoint = [&](const uint32_t k0) {  // k0 = c BWD_CH: checkpoint c - 1
             float s0 = C0 + qperm<QP_X1>(C0), s1 = C1 + qperm<QP_X1>(C1), s2 = C2 + qperm<QP_X1>(C2);
             s0 += qperm<QP_X2>(s0);
             s1 += qperm<QP_X2>(s1);
             s2 += qperm<QP_X2>(s2);
-            if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)nck) * 64 + pix_q] = make_float4(fabsf(T), s0, s1, s2);
-            nck++;
+            nck = (int)(k0 / BWD_CH);  // (they come in order)
+            if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)(nck - 1)) * 64 + pix_q] = make_float4(fabsf(T), s0, s1, s2);
             if (tid == 0) ck_start[quad * (size_t)chunks + nck] = k0;
-            next_ck = k0 + BWD_CH;
+        };
+        // the next chunk boundary this batch can meet (steps start at multiples of four: every c BWD_CH is a step boundary;
+        // one before kbase -- lead > 0 -- was this step's boundary in the previous batch already), or none
+        uint32_t ck_next = 0xFFFFFFFFu;
+        if (chunks > 1) {
+            const uint32_t k = (max(kbase, 1u) + BWD_CH - 1u) & ~(BWD_CH - 1u);
+            if (k < (uint32_t)chunks * BWD_CH) ck_next = k;
+        }
+        auto ck_due = [&](const uint32_t k) {
+            if (k != ck_next) return false;
+            ck_next = (k + BWD_CH < (uint32_t)chunks * BWD_CH) ? k + BWD_CH : 0xFFFFFFFFu;
+            return true;
         };
         const char* sp = reinterpret_cast<const char*>(srec) + e * 48;
-        uint32_t idx1 = kbase + (uint32_t)e + 1u;  // compacted index of this lane's entry, 1-based
+        const uint32_t kstep0 = kbase - lead;              // compacted index of the batch's first step (its lead entries: done)
+        const int nstaged = (int)lead + cnt;
+        uint32_t idx1 = kstep0 + (uint32_t)e + 1u;         // compacted index of this lane's entry, 1-based
         // one step: the four entries a / b / c hold (one per lane of the quad) against the wave's 16 pixels
         auto step = [&](const float4 a, const float2 b, const float4 c) {
             const float dx = a.x - pxf, dy = a.y - pyf;
@@ -391,18 +449,18 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         float4 a0 = ld_a(0), c0 = ld_c(0);
         float2 b0 = ld_b(0);
         int j = 0;
-        for (; j + 4 < cnt; j += 8) {
-            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);  // (workgroup-uniform)
+        for (; j + 4 < nstaged; j += 8) {
+            if (ck_due(kstep0 + (uint32_t)j)) checkpoint(kstep0 + (uint32_t)j);  // (workgroup-uniform)
             const float4 a1 = ld_a(192), c1 = ld_c(192);
             const float2 b1 = ld_b(192);
             step(a0, b0, c0);
-            if (nck + 1 < chunks && kbase + (uint32_t)j + 4u >= next_ck) checkpoint(kbase + (uint32_t)j + 4u);
+            if (ck_due(kstep0 + (uint32_t)j + 4u)) checkpoint(kstep0 + (uint32_t)j + 4u);
             a0 = ld_a(384); c0 = ld_c(384); b0 = ld_b(384);
             sp += 384;
             step(a1, b1, c1);
         }
-        if (j < cnt) {
-            if (nck + 1 < chunks && kbase + (uint32_t)j >= next_ck) checkpoint(kbase + (uint32_t)j);
+        if (j < nstaged) {
+            if (ck_due(kstep0 + (uint32_t)j)) checkpoint(kstep0 + (uint32_t)j);
             step(a0, b0, c0);
         }
         {
@@ -410,7 +468,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             lk = max(lk, qperm<QP_X2>(lk));
             last_k = lk;  // the pixel's last contributor so far
             // its position in the TILE's list (n_contrib), looked up once per batch
-            if (lk > kbase) last = __float_as_uint(srec[(lk - 1u - kbase) * 3 + 2].w);
+            if (lk > kbase) last = __float_as_uint(srec[(lk - 1u - kstep0) * 3 + 2].w);
         }
         const bool alive = __ballot(T > 0.f) != 0ull;
         if (lane == 0) s_flag[wv] = alive ? 1u : 0u;
@@ -433,7 +491,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         const size_t pid = (size_t)py * W + px;
         const float Tf = fabsf(T);
         final_T[pid] = Tf;
-        n_contrib[pid] = last;
+        n_contrib[pid] = FQ ? A.src_n_contrib[pid] : last;
         ncon_c[pid] = last_k;
         out_color[pid] = s0 + Tf * bg[0];
         out_color[HW + pid] = s1 + Tf * bg[1];
@@ -445,17 +503,18 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
 // total (tile_order_kernel marks them in the launch order) are rendered by all four waves, four entries per step; the
 // others by the first wave alone, as on large images -- there the chip is busy anyway and the one-entry step does the
 // same work in 0.6 x the instructions.
+template <bool FQ>
 __global__ __launch_bounds__(FWD4_BATCH) void render_fwd_small_kernel(const FwdArgs A) {
-    __shared__ float4 srec[(FWD4_BATCH + 8) * 3];
+    __shared__ float4 srec[(FWD4_BATCH + 12) * 3];
     __shared__ uint32_t s_cnt[4], s_flag[4], s_lastk[4];
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot >= A.ntiles) return;
     const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
     if (ov >> 31) {
-        render_quadrant_4(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
+        render_quadrant_4<FQ>(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
     } else if (threadIdx.x < 64) {
-        render_quadrant_1(A, (int)ov, q, srec);  // (no workgroup barrier inside: the other waves have left)
+        render_quadrant_1<FQ>(A, (int)ov, q, srec);  // (no workgroup barrier inside: the other waves have left)
     }
 }
 
@@ -466,13 +525,18 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
-                    ql.ckpt ? ql.chunks : 1};
+                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib};
+    const dim3 grid(render_grid_blocks(gx * gy, xmap));
+    const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
     // tile_order_kernel marked the tile's list as long
-    if (ql.four_waves)
-        hipLaunchKernelGGL(render_fwd_small_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(FWD4_BATCH), 0, s, A);
-    else
-        hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid_blocks(gx * gy, xmap)), dim3(64), 0, s, A);
+    if (ql.four_waves) {
+        if (fq) hipLaunchKernelGGL(render_fwd_small_kernel<true>, grid, dim3(FWD4_BATCH), 0, s, A);
+        else hipLaunchKernelGGL(render_fwd_small_kernel<false>, grid, dim3(FWD4_BATCH), 0, s, A);
+    } else {
+        if (fq) hipLaunchKernelGGL(render_fwd_kernel<true>, grid, dim3(64), 0, s, A);
+        else hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(64), 0, s, A);
+    }
     GS_LAUNCH_CHECK("render_forward", 0, s);
     return GS_OK;
 }
