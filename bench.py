@@ -364,10 +364,15 @@ def main(argv=None):
         # nothing may leave the GPU idle between them and the timed loop -- and keep it off until the timing is done.
         gc.collect()
         gc.disable()
+        # ... over the frames the warm-up and the timed loop will render (at least once each): the pair count differs from
+        # frame to frame, and a binning capacity or scratch size the caching allocator has not seen yet is a hipMalloc of
+        # milliseconds -- inside a timed region of 20 steps one of those is 20 % of the reading
         t_end = time.perf_counter() + 0.7
-        while time.perf_counter() < t_end:
-            for i in range(8):
-                step(i)
+        nf, i = len(cams), 0
+        while time.perf_counter() < t_end or i < nf:
+            for _ in range(8):
+                step(i % nf)
+                i += 1
             torch.cuda.synchronize()
         for i in range(Wm):
             step(8 + i)
