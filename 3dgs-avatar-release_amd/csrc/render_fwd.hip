@@ -45,6 +45,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, not for its global ones
+// (__syncthreads() also drains vmcnt: the prefetched records in flight and the qlist store of the batch)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One wave, one quadrant (tile, q), one entry per step.  `srec`: LDS for 66 staged entries (64 + the two the pipelined
 // loop may read past a batch).
 template <bool FQ>
@@ -101,6 +107,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     }
     if (live && 64 + lane < n) pid_n = list[64 + lane];
     for (int base = 0; base < n && live; base += 64) {
+        asm volatile("" : "+v"(pid_n));  // (waited for here, not behind this batch's qlist store: render_quadrant_4)
         Staged s;
         bool hit;
         if (FQ) {
@@ -330,6 +337,9 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     }
     if (live && FWD4_BATCH + tid < n) pid_n = list[FWD4_BATCH + tid];
     for (int base = 0; base < n && live; base += FWD4_BATCH) {
+        // (the index fetched two batches ahead is waited for HERE, where everything older has long arrived: left pending,
+        // the compiler waits for it -- vmcnt(0), i.e. for this batch's qlist store too -- right before the next prefetch)
+        asm volatile("" : "+v"(pid_n));
         Staged s;
         bool hit;
         if (FQ) {
@@ -340,7 +350,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         }
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
-        __syncthreads();  // (the previous batch's readers of srec are done, too)
+        lds_barrier();  // (the previous batch's readers of srec are done, too)
         const uint32_t n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
         const int cnt = (int)(n0 + n1 + n2 + n3);
         const uint32_t woff = wv == 0 ? 0u : (wv == 1 ? n0 : (wv == 2 ? n0 + n1 : n0 + n1 + n2));
@@ -366,7 +376,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
                 srec[zs * 3 + 2] = z;
             }
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t kbase = kcount;  // compacted index of this batch's first entry
         kcount += (uint32_t)cnt;
         if (base + FWD4_BATCH + tid < n) {
@@ -472,13 +482,13 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         }
         const bool alive = __ballot(T > 0.f) != 0ull;
         if (lane == 0) s_flag[wv] = alive ? 1u : 0u;
-        __syncthreads();
+        lds_barrier();
         live = (s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) != 0u;  // every pixel of the quadrant frozen: stop
     }
     {
         const uint32_t wm = wave_max_u32(last_k);
         if (lane == 0) s_lastk[wv] = wm;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) qcount[quad] = max(max(s_lastk[0], s_lastk[1]), max(s_lastk[2], s_lastk[3]));
         if (chunks > 1 && tid > nck && tid < chunks) ck_start[quad * (size_t)chunks + tid] = 0xFFFFFFFFu;  // never begun
     }
