@@ -368,7 +368,7 @@ int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, floa
 static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
                          size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
                          const float* dL_dpix, const float* dL_dopacity_img, void* scratch, size_t scratch_bytes,
-                         const GsGrads* gr, void* stream) {
+                         const GsGrads* gr, void* stream, const GsSecondImage* second = nullptr) {
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch)) return GS_E_BAD_ARG;
@@ -395,9 +395,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.ncon_c = (uint32_t*)(im + I.ncon_c);
         ql.qcount = (uint32_t*)(im + I.tile_nmax);
         ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
-    ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
         ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
-    ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
+        ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
@@ -406,10 +405,18 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
                                PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1}, LongLists{0, nullptr},
                                a->debug, s); }
         if (rc != GS_OK) return rc;
+        SecondImage si{nullptr, nullptr, nullptr, nullptr};
+        if (second) {
+            // the second render's own image state: its checkpoints (same chunk boundaries: same geometry, same rule)
+            const ImgLayout I2 = img_layout(a->W, a->H, second->long_lists);
+            if (second->img_bytes < I2.total || I2.bwd_chunks != I.bwd_chunks) return GS_E_BAD_ARG;
+            si = SecondImage{second->colors, second->out_color, second->dL_dpix,
+                             ql.chunks > 1 ? (const float4*)((const char*)second->img + I2.ckpt) : nullptr};
+        }
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
                                     out_color, dL_dpix, dL_dopacity_img, (const float*)(im + I.final_T), a->bg, (float*)scratch, q8,
-                                    s); }
+                                    second ? &si : nullptr, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -437,6 +444,15 @@ int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const voi
     if (!dL_dopacity_img) return GS_E_BAD_ARG;
     return backward_impl(a, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, dL_dpix,
                          dL_dopacity_img, scratch, scratch_bytes, gr, stream);
+}
+
+int gs_backward_with_second(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
+                            const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                            const float* out_color, const float* dL_dpix, const GsSecondImage* second, void* scratch,
+                            size_t scratch_bytes, const GsGrads* grads, void* stream) {
+    if (!second || !second->colors || !second->out_color || !second->dL_dpix || !second->img) return GS_E_BAD_ARG;
+    return backward_impl(a, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, dL_dpix, nullptr,
+                         scratch, scratch_bytes, grads, stream, second);
 }
 
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -340,9 +340,20 @@ struct QuadLists {
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
                           const QuadLists& ql, hipStream_t s);
+// a second image rendered from the same geometry with other colours (gs_forward_shared: the reference's opacity pass
+// with colours = 1, gaussian_renderer/__init__.py:132-142), differentiated in the SAME pass: alpha and T are shared,
+// so dL/dalpha is linear in (c . g) summed over both images -- one more dot product per step and one more term in
+// Gtot; the gradient of the second image's colours is not produced (they are constants)
+struct SecondImage {
+    const float* colors;     // [P,3]
+    const float* out_color;  // [3,H,W] the second render
+    const float* dL_dpix;    // [3,H,W]
+    const float4* ckpt;      // its checkpoints (chunked backward), or null
+};
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
-                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s);
+                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
+                           hipStream_t s);
 // opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,

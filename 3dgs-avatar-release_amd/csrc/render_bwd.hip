@@ -84,15 +84,22 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
         : "scc");
 }
 
-// the nine per-entry values the inner loop reads
-struct Entry {
+// the nine per-entry values the inner loop reads (+ the entry's colour in a second image of the same geometry)
+template <bool SECOND>
+struct EntryT {
     float x, y, A2, B2, C2, o, r, g, b;
 };
+template <>
+struct EntryT<true> {
+    float x, y, A2, B2, C2, o, r, g, b, r2, g2, b2;
+};
+
 
 // OPA: the image has a fourth channel whose "colour" is 1 for every Gaussian -- the opacity render the reference
 // obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
 // that channel: one more term in (c . g) and in Gtot, nothing else changes.
-template <bool OPA>
+// MODE 0: one image; 1 (OPA): + the opacity channel; 2 (SECOND): + a second image of the same geometry
+template <int MODE>
 __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order, int W, int H, int gx,
@@ -107,13 +114,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8,
                                                         const float4* __restrict__ ckpt,
                                                         const uint32_t* __restrict__ ck_start, const int chunks,
-                                                        const int blocks_per_chunk) {
+                                                        const int blocks_per_chunk, const SecondImage second) {
+    constexpr bool OPA = MODE == 1, SECOND = MODE == 2;
+    typedef EntryT<SECOND> Entry;
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
     // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
-    __shared__ float pix[OPA ? 7 : 6][4 * RING_STRIDE];  // (+ the opacity channel's gradient)
+    __shared__ float pix[OPA ? 7 : (SECOND ? 9 : 6)][4 * RING_STRIDE];  // (+ the opacity channel's gradient / the second image's)
     int slot, q;
     // chunk-major: all first chunks, heaviest tiles first, then all second chunks, ... (chunks = 1: one wave per quadrant)
     const int chunk = chunks > 1 ? (int)blockIdx.x / blocks_per_chunk : 0;
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         // (g0, g1, g2, Gtot) and (x, y, lim): the pixel at position i of its ring meets compacted entry k at
         // step s = k + i, and the pair counts only while k < (its last contributor) <=> s < lim = ncon + i
         float4 c0 = zero4, c1 = make_float4((float)px, (float)py, __uint_as_float((uint32_t)j), 0.f);
+        float3 h = make_float3(0.f, 0.f, 0.f);  // (SECOND) dL/dpixel of the second image
         if (px < W && py < H) {
             const size_t HW = (size_t)H * W;
             const size_t pid = (size_t)py * W + px;
@@ -153,12 +163,21 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                 c1.w = dL_dopa[pid];
                 c0.w += ((1.0f - Tf) + Tf * bg[0]) * c1.w;  // the opacity channel's share of Gtot
             }
+            if (SECOND) {
+                h = make_float3(second.dL_dpix[pid], second.dL_dpix[HW + pid], second.dL_dpix[2 * HW + pid]);
+                c0.w += second.out_color[pid] * h.x + second.out_color[HW + pid] * h.y + second.out_color[2 * HW + pid] * h.z;
+            }
             if (chunk > 0) {
                 // the forward's state before entry k0: T, and the colour composited so far (the opacity channel's is 1 - T)
-                const float4 ck = ckpt[((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)(chunk - 1)) * 64 + lane];
+                const size_t ci = ((size_t)(tile * 4 + q) * (size_t)(chunks - 1) + (size_t)(chunk - 1)) * 64 + lane;
+                const float4 ck = ckpt[ci];
                 T0 = ck.x;
                 c0.w -= ck.y * g0 + ck.z * g1 + ck.w * g2;
                 if (OPA) c0.w -= (1.0f - ck.x) * c1.w;
+                if (SECOND) {
+                    const float4 ck2 = second.ckpt[ci];  // (the second render's own checkpoints: same T, its colours)
+                    c0.w -= ck2.y * h.x + ck2.z * h.y + ck2.w * h.z;
+                }
             }
         }
         const int slot = ring * RING_STRIDE + j;
@@ -169,6 +188,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         pix[4][slot] = pix[4][slot + RING] = c1.y;
         pix[5][slot] = pix[5][slot + RING] = c1.z;
         if (OPA) pix[6][slot] = pix[6][slot + RING] = c1.w;
+        if (SECOND) {
+            pix[6][slot] = pix[6][slot + RING] = h.x;
+            pix[7][slot] = pix[7][slot + RING] = h.y;
+            pix[8][slot] = pix[8][slot + RING] = h.z;
+        }
         gtot0 = c0.w;
     }
 
@@ -183,20 +207,26 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
         row = (off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx)) * 4u + (uint32_t)q;
     };
+    float3 q2 = make_float3(0.f, 0.f, 0.f);  // (SECOND) the gathered entry's colour in the second image
     auto gather = [&](int k, float4& p0, float4& p1, float4& p2) {
         if (k < m) {
             const uint32_t id = qlist[qbase + k];
             p0 = rec[(size_t)id * 3];
             p1 = rec[(size_t)id * 3 + 1];
             p2 = rec[(size_t)id * 3 + 2];
+            if (SECOND) q2 = make_float3(second.colors[(size_t)id * 3], second.colors[(size_t)id * 3 + 1], second.colors[(size_t)id * 3 + 2]);
         }
+    };
+    auto convert2 = [&](Entry& e) {  // (after convert, before the next gather)
+        if constexpr (SECOND) { e.r2 = q2.x; e.g2 = q2.y; e.b2 = q2.z; }
     };
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
-    Entry cur = {0, 0, 0, 0, 0, 0, 0, 0, 0}, nxt = cur;
+    Entry cur = {}, nxt = {};
     uint32_t nxt_row = 0;  // gradient row (4 pair + quadrant) of the entry in `nxt`
     gather(j, p0, p1, p2);              // (the four rings hold the same entries)
     convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by position t of every ring at step t
+    convert2(nxt);
     gather(RING + j, p0, p1, p2);       // chunk 1 in flight during round 0
     __syncthreads();
 
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
     // index into pix[c][] of the pixel at this lane: ring base + (s - j) mod 16, + 16 within a round
     uint32_t pidx = (uint32_t)(ring * RING_STRIDE + ((RING - j) & (RING - 1)));
-    constexpr int NPC = OPA ? 7 : 6;
+    constexpr int NPC = OPA ? 7 : (SECOND ? 9 : 6);
     float pc[NPC];
 #pragma unroll
     for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
@@ -253,6 +283,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                 if (ring == 0) write_row(rowX, X);
             }
             convert(p0, p1, p2, nxt, nxt_row);
+            convert2(nxt);
             gather(s0 + RING + j, p0, p1, p2);
             pidx -= (uint32_t)RING;
         }
@@ -267,7 +298,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[3], pyf = pc[4];
             const uint32_t lim = __float_as_uint(pc[5]);
-            const float g4 = OPA ? pc[NPC - 1] : 0.f;
+            const float g4 = OPA ? pc[6] : 0.f;
+            const float h0 = SECOND ? pc[6] : 0.f, h1 = SECOND ? pc[7] : 0.f, h2 = SECOND ? pc[8] : 0.f;
             // next step's pixel constants, fetched now
             pidx += 1u;
 #pragma unroll
@@ -287,7 +319,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float alpha = valid ? a2 : 0.f;
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
-            const float cg = OPA ? (cur.r * g.x + cur.g * g.y + cur.b * g.z) + g4 : cur.r * g.x + cur.g * g.y + cur.b * g.z;
+            float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
+            if constexpr (OPA) cg += g4;
+            if constexpr (SECOND) cg += cur.r2 * h0 + cur.g2 * h1 + cur.b2 * h2;
             Rem = __builtin_fmaf(-cg, wgt, Rem);
             const float one_m = 1.f - alpha;
             const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
@@ -331,20 +365,25 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
-                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, hipStream_t s) {
+                           const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
+                           hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const int chunks = ql.ckpt ? ql.chunks : 1;
     const int bpc = render_grid_blocks(gx * gy, xmap);
     const dim3 grid((unsigned)bpc * (unsigned)chunks);
-    if (dL_dopa)
-        hipLaunchKernelGGL(render_bwd_kernel<true>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, ql.ck_start, chunks, bpc);
+    const SecondImage none{nullptr, nullptr, nullptr, nullptr};
+#define GS_BWD_ARGS                                                                                                       \
+    reinterpret_cast<const float4*>(rec), reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, \
+        ql.ncon_c, ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt,    \
+        ql.ck_start, chunks, bpc
+    if (second)
+        hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);
+    else if (dL_dopa)
+        hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);
     else
-        hipLaunchKernelGGL(render_bwd_kernel<false>, grid, dim3(64), 0, s, reinterpret_cast<const float4*>(rec),
-                           reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, ql.ncon_c,
-                           ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt, ql.ck_start, chunks, bpc);
+        hipLaunchKernelGGL(render_bwd_kernel<0>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);
+#undef GS_BWD_ARGS
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;
 }

@@ -46,11 +46,15 @@ _SPECULATE = os.environ.get("GSPLAT_SPECULATE", "1") != "0"
 
 class _GeomEntry(object):
     """Geometry state of ONE forward call (preprocess, sorts, binning), offered to the call that follows it."""
-    __slots__ = ("key", "geom", "binning", "img", "num_rendered", "capacity", "radii", "__weakref__")
+    __slots__ = ("key", "geom", "binning", "img", "num_rendered", "capacity", "radii", "color_ref", "means2D_id",
+                 "allow_second", "second", "long_lists", "__weakref__")
 
     def __init__(self, key, geom, binning, img, num_rendered, capacity, radii):
         self.key, self.geom, self.binning, self.img, self.radii = key, geom, binning, img, radii
         self.num_rendered, self.capacity = num_rendered, capacity  # the frame's pair count / what `binning` is carved for
+        # for the fused backward of a second render of this geometry (_second_render_dependency): the producing call's
+        # image (weak), its means2D, whether it can take a second image along, and what the second call left for it
+        self.color_ref, self.means2D_id, self.allow_second, self.second, self.long_lists = None, None, False, None, 0
 
     def release(self):
         self.key = self.geom = self.binning = self.img = self.radii = None
@@ -239,23 +243,58 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                         raster_settings, with_opacity=False):
     """(color, radii), as upstream.  with_opacity=True (an extension; see GaussianRasterizer.forward) adds the
     opacity render as a third result, computed and differentiated inside the same pass."""
+    dep = None
+    if (_FUSE_SECOND and _SHARE and not with_opacity and torch.is_grad_enabled() and colors_precomp is not None
+            and colors_precomp.numel() and not colors_precomp.requires_grad and (sh is None or sh.numel() == 0)):
+        dep = _second_render_dependency(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
     color, radii, opacity = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                       cov3Ds_precomp, raster_settings, bool(with_opacity))
+                                                       cov3Ds_precomp, raster_settings, bool(with_opacity), dep)
     return (color, radii, opacity) if with_opacity else (color, radii)
+
+
+# The reference's render() rasterizes the opacity image with a second call on the same geometry, colours = constant ones
+# (gaussian_renderer/__init__.py:132-142), and each call has its own backward: two full passes over the tile lists.  The
+# two images share alpha and T, so their gradients w.r.t. the shared inputs can come out of ONE pass
+# (gs_backward_with_second).  When the second call meets the first call's geometry on offer and its colours need no
+# gradient, it takes the FIRST call's image as an extra autograd input: its own backward then runs before the first
+# call's (a true dependency, not an ordering accident), hands its gradient image over and returns no gradients; the first
+# call's backward returns the sum of both.  GSPLAT_FUSE_SECOND_BACKWARD=0 keeps the two backwards apart.
+_FUSE_SECOND = os.environ.get("GSPLAT_FUSE_SECOND_BACKWARD", "1") != "0"
+
+
+def _second_render_dependency(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, settings):
+    """The image of the call that just ran, if THIS call is a second render of its geometry (what `take` will find)."""
+    if not means3D.is_cuda:
+        return None
+    ref = _geom_cache.offer.get(means3D.device.index)
+    e = ref() if ref is not None else None
+    if e is None or e.key is None or not e.allow_second or e.color_ref is None or e.means2D_id != id(means2D):
+        return None
+    img1 = e.color_ref()
+    if img1 is None or not img1.requires_grad:
+        return None
+    def c(t):
+        return t if (t is None or t.numel() == 0 or (t.dtype == torch.float32 and t.is_contiguous())) else None
+    if any(c(t) is None and t is not None and t.numel() for t in (means3D, opacities, scales, rotations, cov3Ds_precomp)):
+        return None  # (the forward would render from converted copies: no identity to match)
+    key = _geom_cache.key(settings, means3D, opacities, scales, rotations, cov3Ds_precomp)
+    if e.key["scalars"] != key["scalars"] or e.key["sigs"] != key["sigs"]:
+        return None
+    return img1
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, with_opacity=False):
+                raster_settings, with_opacity=False, dep=None):
         if not raster_settings.debug:
             return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                cov3Ds_precomp, raster_settings, with_opacity)
+                                                cov3Ds_precomp, raster_settings, with_opacity, dep)
         # upstream's debug mode: the arguments are kept aside and written to snapshot_fw.dump if the native call fails
         args = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         try:
             return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                cov3Ds_precomp, raster_settings, with_opacity)
+                                                cov3Ds_precomp, raster_settings, with_opacity, dep)
         except Exception:
             _dump_snapshot("snapshot_fw.dump", raster_settings, args)
             print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
@@ -263,8 +302,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                 raster_settings, with_opacity=False):
+                 raster_settings, with_opacity=False, dep=None):
         ctx.with_opacity = bool(with_opacity)
+        ctx.defer_to = None
+        means2D_in = means2D
         # outputs nothing downstream differentiates (always: radii) arrive as None in backward instead of as freshly
         # filled zero tensors -- one fill launch over P ints per step otherwise
         ctx.set_materialize_grads(False)
@@ -307,6 +348,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # same geometry and camera as the call just before: new colours only
                 num_rendered, capacity = hit.num_rendered, hit.capacity
                 binning = hit.binning
+                if (dep is not None and hit.allow_second and hit.color_ref is not None and hit.color_ref() is dep
+                        and hit.long_lists == int(a.long_lists)):
+                    ctx.defer_to = hit  # this call's backward hands its gradient to the producing call's (below)
                 bin_bytes = binning.numel()
                 radii.copy_(hit.radii)
                 color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -351,6 +395,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             if share:
                 # offered to the next call; owned by this call's autograd node (ctx), not by the cache
                 ctx.geom_entry = _GeomEntry(gkey, geom, binning, img, num_rendered, capacity, radii)
+                ctx.geom_entry.color_ref = weakref.ref(color)  # (the tensor this call returns: autograd tracks it)
+                ctx.geom_entry.means2D_id = id(means2D_in)
+                ctx.geom_entry.allow_second = not ctx.with_opacity
+                ctx.geom_entry.long_lists = int(a.long_lists)
                 _geom_cache.put(dev, ctx.geom_entry)
             return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color,
@@ -394,8 +442,18 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
         L = _lib.load()
+        tgt = getattr(ctx, "defer_to", None)
+        if tgt is not None and tgt.geom is not None and grad_out_color is not None:
+            # a second render of another call's geometry (see _second_render_dependency): that call's backward, which runs
+            # after this one, differentiates both images in one pass
+            saved = ctx.saved_tensors
+            tgt.second = dict(colors=saved[2], out_color=saved[11], grad=_f32c(grad_out_color, "grad_out_color"), img=saved[10],
+                              long_lists=ctx.long_lists)
+            return (None,) * 11
         entry = getattr(ctx, "geom_entry", None)
+        second = None
         if entry is not None:  # a render after this backward (e.g. after an optimiser step) must not meet this state
+            second, entry.second = entry.second, None
             entry.release()
             ctx.geom_entry = None
         (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
@@ -434,7 +492,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = torch.empty(P, 4, **f) if has_sr else None
             gr = _lib.GsGrads(_lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_sh), _lib.ptr(d_colors),
                               _lib.ptr(d_opacity), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov3D))
-            if g_op is None:
+            if second is not None and g_op is None:
+                si = _lib.GsSecondImage(second["colors"].data_ptr(), second["out_color"].data_ptr(), second["grad"].data_ptr(),
+                                        second["img"].data_ptr(), second["img"].numel(), int(second["long_lists"]))
+                _lib.check(L.gs_backward_with_second(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
+                                                     binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
+                                                     color.data_ptr(), g.data_ptr(), ctypes.byref(si), scratch.data_ptr(),
+                                                     scratch_bytes, ctypes.byref(gr), sptr))
+            elif g_op is None:
                 _lib.check(L.gs_backward(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
                                          binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
                                          color.data_ptr(), g.data_ptr(), scratch.data_ptr(), scratch_bytes,
@@ -446,7 +511,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                       color.data_ptr(), g.data_ptr(), g_op.data_ptr(), scratch.data_ptr(),
                                                       scratch_bytes, ctypes.byref(gr), sptr))
         return (d_means3D, d_means2D, d_sh, d_colors if has_col else None, d_opacity, d_scales, d_rot,
-                d_cov3D if has_cov else None, None, None)
+                d_cov3D if has_cov else None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):

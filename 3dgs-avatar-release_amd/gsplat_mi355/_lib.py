@@ -21,6 +21,11 @@ class GsFwdArgs(ctypes.Structure):
     ]
 
 
+class GsSecondImage(ctypes.Structure):  # include/gsplat_mi355.h: GsSecondImage
+    _fields_ = [("colors", c_void_p), ("out_color", c_void_p), ("dL_dpix", c_void_p), ("img", c_void_p),
+                ("img_bytes", c_size_t), ("long_lists", c_int32)]
+
+
 class GsGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dsh", "dL_dcolors", "dL_dopacity",
                                         "dL_dscales", "dL_drotations", "dL_dcov3D")]
@@ -32,7 +37,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
-           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for"]
+           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_ADAM_MAX_TENSORS = 16
@@ -79,6 +84,9 @@ def load():
         L.gs_backward_with_opacity.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
                                                c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(GsGrads),
                                                c_void_p]
+        L.gs_backward_with_second.argtypes = [POINTER(GsFwdArgs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                                              c_size_t, c_int64, c_void_p, c_void_p, POINTER(GsSecondImage), c_void_p, c_size_t,
+                                              POINTER(GsGrads), c_void_p]
         L.gs_mark_visible.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.knn_workspace_bytes.argtypes = [c_int32, POINTER(c_size_t)]
         L.knn_dist2.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]

@@ -165,6 +165,25 @@ int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const voi
                              const float* dL_dopacity_img, void* scratch, size_t scratch_bytes, const GsGrads* grads,
                              void* stream);
 
+/* A SECOND image rendered from the same geometry with other colours (gs_forward_shared: the reference's opacity pass,
+ * gaussian_renderer/__init__.py:132-142) differentiated in the same pass as the first: alpha and T are shared, so the
+ * second image adds one dot product per (pixel, Gaussian) step and one term to Gtot instead of a whole second backward.
+ * The gradients are the SUM of both images' gradients w.r.t. the shared inputs; the second image's colours get none
+ * (they must be constants); dL_dcolors / dL_dsh are the first image's.  `img` = the image state gs_forward_shared
+ * filled for the second render (its checkpoints), `long_lists` the value that render was given. */
+typedef struct GsSecondImage {
+    const float* colors;    /* [P,3] colors_precomp of the second render */
+    const float* out_color; /* [3,H,W] its result */
+    const float* dL_dpix;   /* [3,H,W] its gradient */
+    const void* img;        /* its image state */
+    size_t img_bytes;
+    int32_t long_lists;
+} GsSecondImage;
+int gs_backward_with_second(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
+                            const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                            const float* out_color, const float* dL_dpix, const GsSecondImage* second, void* scratch,
+                            size_t scratch_bytes, const GsGrads* grads, void* stream);
+
 /* ---- upstream mark_visible / GaussianRasterizer.markVisible: present[i] = (z_view > 0.2) ---- */
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);
