@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void first_pair_kernel(const uint32_t* __restr
         const unsigned long long total =
             block_base + wave_tiles[w0] + wave_tiles[w0 + 1] + wave_tiles[w0 + 2] + wave_tiles[w0 + 3];
         count[0] = total;
+        count[2] = 0ull;  // (see ds_count_kernel)
         // ... and straight into the caller's pinned host word, which the host is polling: the pair count
         // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
         if (host_count) __hip_atomic_store(host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -22,6 +22,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_BWD_CHUNKS].store(1);
     g_tune[GS_TUNE_FWD4].store(1);
     g_tune[GS_TUNE_SHARED_QLIST].store(1);
+    g_tune[GS_TUNE_ONES_FAST].store(1);
     g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
 }
 int gs_tune_get(int key) {
@@ -131,7 +132,7 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     char* g = (char*)geom;
     unsigned long long* count = (unsigned long long*)(g + L.count);
     if (a->P == 0) {
-        hipError_t e = hipMemsetAsync(count, 0, 8, s);
+        hipError_t e = hipMemsetAsync(count, 0, 24, s);
         if (e != hipSuccess) { gs_set_error((int)e, "count.memset"); return GS_E_HIP; }
     } else {
         uint32_t* k0 = (uint32_t*)(g + L.key0);
@@ -321,10 +322,15 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     char* b = (char*)binning;
     char* im = (char*)img;
     const int ntiles = I.gx * I.gy;
+    unsigned long long* not_ones = nullptr;
     if (a->P > 0) {
         StageScope sc_("recolor", s);
+        // (the first render's geom state carries the "not all ones" word, zero since that render; the caller passes the
+        // SAME long_lists as to the first render, so that both image states have the same layout)
+        not_ones = (gs_tune_get(GS_TUNE_ONES_FAST) && gs_tune_get(GS_TUNE_SHARED_QLIST) && a->colors_precomp && D > 0)
+                       ? (unsigned long long*)(const_cast<char*>(gs) + L.count) + 2 : nullptr;
         rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
-                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), s);
+                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, s);
         if (rc != GS_OK) return rc;
     }
     // the new image state needs its own copy of the tile ranges and launch order (its backward reads them)
@@ -339,6 +345,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     if (gs_tune_get(GS_TUNE_SHARED_QLIST)) {
         ql.src_qcount = (const uint32_t*)(is + I.tile_nmax);  // (the fields before the checkpoints sit at the same offsets
         ql.src_n_contrib = (const uint32_t*)(is + I.n_contrib);  //  whatever long_lists the first render was given)
+        ql.not_ones = not_ones;
     }
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
@@ -349,6 +356,13 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
                                (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
                                (uint32_t*)(im + I.n_contrib), ql, s); }
     if (rc != GS_OK) return rc;
+    if (ql.not_ones) {  // ... or, colours all ones, the image from the first render's transmittance
+        StageScope sc_("second_ones", s);
+        rc = launch_second_ones(a->bg, a->W, a->H, ql, (const float*)(is + I.final_T), (const uint32_t*)(is + I.ncon_c),
+                                (const float4*)(is + I.ckpt), (const uint32_t*)(is + I.ck_start), out_color,
+                                (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s);
+        if (rc != GS_OK) return rc;
+    }
     if (a->debug) {
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) { gs_set_error((int)e, "render_forward"); return GS_E_HIP; }
@@ -669,6 +683,7 @@ int gs_tuning(const char* name, int value) {
     tune_defaults();
     if (strcmp(name, "xcd_map") == 0) { g_tune[GS_TUNE_XCD_MAP].store(value); return GS_OK; }
     if (strcmp(name, "small_tiles") == 0) { g_tune[GS_TUNE_SMALL_TILES].store(value); return GS_OK; }  // changes the image state's size
+    if (strcmp(name, "ones_fast") == 0) { g_tune[GS_TUNE_ONES_FAST].store(value); return GS_OK; }
     if (strcmp(name, "shared_qlist") == 0) { g_tune[GS_TUNE_SHARED_QLIST].store(value); return GS_OK; }
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only

@@ -121,7 +121,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 // process-wide tuning switches (gs_tuning)
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_COUNT = 8 };
 int gs_tune_get(int key);
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
@@ -245,7 +245,7 @@ struct RankOut { const float* rec; const uint32_t* tiles; uint32_t* sorted_idx; 
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
-                   uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s);
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
@@ -333,6 +333,7 @@ struct QuadLists {
     // forward of a second render of the same geometry: the first render's per-quadrant counts and n_contrib (or null)
     const uint32_t* src_qcount = nullptr;
     const uint32_t* src_n_contrib = nullptr;
+    const unsigned long long* not_ones = nullptr;  // (zero: that render's colours are all ones -- second_ones_kernel renders)
     float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
     uint32_t* ck_start = nullptr;  // [quadrant][chunks]: compacted index every chunk starts at
     int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)
@@ -354,6 +355,9 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
                            hipStream_t s);
+int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
+                       const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
+                       uint32_t* n_contrib, hipStream_t s);
 // opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
         if (blockIdx.x == gridDim.x - 1 && tid == 0) {
             const unsigned long long total = block_base + s_wave[WPB];
             pn.count[0] = total;
+            pn.count[2] = 0ull;  // "a second render's colours are not all ones" (recolor_kernel), for that render's use
             // ... and straight into the caller's pinned host word, which the host is polling: the pair count
             // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
             if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the host reads this word only: no release -- a system-scope release writes the L2 back)

@@ -184,12 +184,14 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
                                                       const float4* __restrict__ rec_src,
                                                       const uint32_t* __restrict__ tiles_src,
                                                       float4* __restrict__ rec_dst, uint32_t* __restrict__ tiles_dst,
-                                                      uint32_t* __restrict__ clamped_dst) {
+                                                      uint32_t* __restrict__ clamped_dst,
+                                                      unsigned long long* __restrict__ not_ones) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float4 r0 = rec_src[(size_t)i * 3], r1 = rec_src[(size_t)i * 3 + 1], r2 = rec_src[(size_t)i * 3 + 2];
     const uint32_t tt = tiles_src[i];
     uint32_t cl = 0;
+    bool bad = false;
     if (tt) {
         float3 col;
         if (colors_precomp) {
@@ -201,6 +203,13 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
         r1.z = col.x;
         r1.w = col.y;
         r2.x = col.z;
+        bad = !(col.x == 1.0f && col.y == 1.0f && col.z == 1.0f);
+    }
+    // `not_ones` (zero since the first render of this geometry): set unless every Gaussian that touches a tile is given
+    // the colour (1, 1, 1) -- the reference's opacity pass -- in which case the image is 1 - T (render_fwd.hip)
+    if (not_ones) {
+        const unsigned long long b = __ballot(bad);  // (one atomic per wave at most, by its first such lane)
+        if (b != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicOr(not_ones, 1ull);
     }
     rec_dst[(size_t)i * 3] = r0;
     rec_dst[(size_t)i * 3 + 1] = r1;
@@ -210,10 +219,10 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
 }
 
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
-                   uint32_t* tiles_dst, uint32_t* clamped_dst, hipStream_t s) {
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, hipStream_t s) {
     hipLaunchKernelGGL(recolor_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.shs,
                        a.colors_precomp, a.campos, reinterpret_cast<const float4*>(rec_src), tiles_src,
-                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst);
+                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst, not_ones);
     GS_LAUNCH_CHECK("recolor", a.debug, s);
     return GS_OK;
 }

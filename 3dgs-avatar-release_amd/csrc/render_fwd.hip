@@ -37,6 +37,9 @@ struct FwdArgs {
     // the quadrants' recorded compacted lists (qlist) are walked instead of the tiles' lists
     const uint32_t* __restrict__ src_qcount;
     const uint32_t* __restrict__ src_n_contrib;
+    // ... and, if not null, a word that is ZERO when that second render's colours are all (1, 1, 1): the render then
+    // leaves at once -- second_ones_kernel writes the image, 1 - T, from the first render's state
+    const unsigned long long* __restrict__ not_ones;
 };
 
 // between two phases of ONE wave that exchange data through LDS (a wave's LDS operations execute in order)
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot >= A.ntiles) return;
+    if (FQ && A.not_ones && *A.not_ones == 0ull) return;
     render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
 }
 
@@ -520,6 +524,7 @@ __global__ __launch_bounds__(FWD4_BATCH) void render_fwd_small_kernel(const FwdA
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot >= A.ntiles) return;
+    if (FQ && A.not_ones && *A.not_ones == 0ull) return;
     const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
     if (ov >> 31) {
         render_quadrant_4<FQ>(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
@@ -535,7 +540,7 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
-                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib};
+                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones};
     const dim3 grid(render_grid_blocks(gx * gy, xmap));
     const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
@@ -560,6 +565,57 @@ __global__ __launch_bounds__(256) void opacity_image_kernel(const float* __restr
     if (i >= n) return;
     const float Tf = final_T[i];
     out[i] = (1.0f - Tf) + Tf * bg[0];
+}
+
+// A second render of the same geometry whose colours are all (1, 1, 1) -- the reference's opacity pass
+// (gaussian_renderer/__init__.py:132-142) -- needs no compositing: every channel is sum_k alpha_k T_k = 1 - T_final, plus
+// T_final bg.  One wave per quadrant writes the image and takes the first render's per-pixel / per-quadrant records over
+// (same geometry: same T, same contributors), checkpoints included (colour composited before a chunk = 1 - T there).
+// Leaves at once unless *not_ones == 0 (recolor_kernel); render_fwd*<true> leave at once if it IS 0.
+struct SecondOnes {
+    const float* src_final_T; const uint32_t* src_n_contrib; const uint32_t* src_ncon_c; const uint32_t* src_qcount;
+    const float4* src_ckpt; const uint32_t* src_ck_start;
+    float* out_color; float* final_T; uint32_t* n_contrib; uint32_t* ncon_c; uint32_t* qcount; float4* ckpt; uint32_t* ck_start;
+    const float* bg; const unsigned long long* not_ones; int W, H, gx, ntiles, chunks;
+};
+__global__ __launch_bounds__(64) void second_ones_kernel(const SecondOnes A) {
+    if (*A.not_ones != 0ull) return;
+    const int quad = blockIdx.x, tile = quad >> 2, q = quad & 3, lane = threadIdx.x;
+    if (tile >= A.ntiles) return;
+    const int tx = tile % A.gx, ty = tile / A.gx;
+    const int px = tx * TILE + 8 * (q & 1) + (lane & 7), py = ty * TILE + 8 * (q >> 1) + (lane >> 3);
+    if (px < A.W && py < A.H) {
+        const size_t HW = (size_t)A.H * A.W, pid = (size_t)py * A.W + px;
+        const float Tf = A.src_final_T[pid];
+        A.final_T[pid] = Tf;
+        A.n_contrib[pid] = A.src_n_contrib[pid];
+        A.ncon_c[pid] = A.src_ncon_c[pid];
+        A.out_color[pid] = (1.0f - Tf) + Tf * A.bg[0];
+        A.out_color[HW + pid] = (1.0f - Tf) + Tf * A.bg[1];
+        A.out_color[2 * HW + pid] = (1.0f - Tf) + Tf * A.bg[2];
+    }
+    if (lane == 0) A.qcount[quad] = A.src_qcount[quad];
+    if (A.chunks > 1) {
+        if (lane < A.chunks) A.ck_start[(size_t)quad * A.chunks + lane] = A.src_ck_start[(size_t)quad * A.chunks + lane];
+        for (int c = 1; c < A.chunks; c++) {
+            if (A.src_ck_start[(size_t)quad * A.chunks + c] == 0xFFFFFFFFu) break;  // (in order: none behind it either)
+            const size_t ci = ((size_t)quad * (size_t)(A.chunks - 1) + (size_t)(c - 1)) * 64 + lane;
+            const float Tc = A.src_ckpt[ci].x;
+            A.ckpt[ci] = make_float4(Tc, 1.0f - Tc, 1.0f - Tc, 1.0f - Tc);
+        }
+    }
+}
+
+int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
+                       const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
+                       uint32_t* n_contrib, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int chunks = ql.ckpt ? ql.chunks : 1;
+    const SecondOnes A{src_final_T, ql.src_n_contrib, src_ncon_c, ql.src_qcount, src_ckpt, src_ck_start, out_color, final_T,
+                       n_contrib, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start, bg, ql.not_ones, W, H, gx, gx * gy, chunks};
+    hipLaunchKernelGGL(second_ones_kernel, dim3((unsigned)(gx * gy * 4)), dim3(64), 0, s, A);
+    GS_LAUNCH_CHECK("second_ones", 0, s);
+    return GS_OK;
 }
 
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s) {

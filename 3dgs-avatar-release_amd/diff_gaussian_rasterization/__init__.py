@@ -328,14 +328,6 @@ class _RasterizeGaussians(torch.autograd.Function):
                            keep)
             stream = torch.cuda.current_stream(dev)
             sptr = ctypes.c_void_p(stream.cuda_stream)
-            geom_bytes = _size("gs_geom_bytes", P)
-            ik = ("img", W, H, int(a.long_lists))
-            img_bytes = _sizes.get(ik)
-            if img_bytes is None:
-                img_bytes = _sizes[ik] = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
-            geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
-            img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
-            radii = torch.empty(P, dtype=torch.int32, device=dev)
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             share = _SHARE and any(ctx.needs_input_grad)  # (true only under grad mode)
             gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream.cuda_stream)
@@ -344,6 +336,18 @@ class _RasterizeGaussians(torch.autograd.Function):
             if not share:
                 _geom_cache.offer.pop(dev.index, None)
             ctx.geom_entry = None
+            if hit is not None:
+                # a second render of that call's geometry runs with ITS long_lists (the statistics word may have changed
+                # since): the two image states then have one layout, which the all-ones render and the one-pass backward need
+                a.long_lists = int(hit.long_lists)
+            geom_bytes = _size("gs_geom_bytes", P)
+            ik = ("img", W, H, int(a.long_lists))
+            img_bytes = _sizes.get(ik)
+            if img_bytes is None:
+                img_bytes = _sizes[ik] = _lib.nbytes(L.gs_image_bytes_for, ctypes.byref(a))
+            geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
+            img = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)
             if hit is not None:
                 # same geometry and camera as the call just before: new colours only
                 num_rendered, capacity = hit.num_rendered, hit.capacity

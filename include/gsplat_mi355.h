@@ -305,7 +305,8 @@ int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches
  * long tile lists; flip them between frames only, "small_tiles" also changes the image state's size): "fwd4" (1: four
  * waves per quadrant, four entries per step on the marked tiles), "bwd_chunks" (1: backward in chunks from the forward's
  * checkpoints), "small_tiles" (images of up to this many tiles use both whatever GsFwdArgs.long_lists says; 2048).  "shared_qlist"
- * (1: gs_forward_shared renders from the recorded quadrant lists, 0: from the tiles' lists; same bits) */
+ * (1: gs_forward_shared renders from the recorded quadrant lists, 0: from the tiles' lists; same bits).  "ones_fast" (1: a
+ * second render whose colours are all ones is written as 1 - T of the first; 0: composited; equal to fp32 rounding) */
 int gs_tuning(const char* name, int value);
 const char* gs_status_string(int code);
 int gs_last_hip_error(void); /* hipError_t of the most recent GS_E_HIP on this thread */

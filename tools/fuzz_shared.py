@@ -21,7 +21,8 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
 trials = 0
-FUSED = len(sys.argv) > 3 and sys.argv[3] == "fused"  # default: each call its own backward (bit for bit); fused: tolerance
+ONES = len(sys.argv) > 3 and sys.argv[3] == "ones"  # the reference's opacity pass: colours = 1, image written as 1 - T
+FUSED = len(sys.argv) > 3 and sys.argv[3] in ("fused", "ones")  # default: each call its own backward (bit for bit); fused: tolerance
 dgr._FUSE_SECOND = FUSED
 worst = 0.0
 while time.time() < t_end:
@@ -39,7 +40,7 @@ while time.time() < t_end:
                                       cam.camera_center.to(dev), False, False)
     gimg = torch.randn(3, H, W, device=dev)
     gop = torch.randn(3, H, W, device=dev)
-    cols0 = torch.rand(n, 3, device=dev)
+    cols0 = torch.ones(n, 3, device=dev) if ONES else torch.rand(n, 3, device=dev)
     res = {}
     for share in (True, False):
         dgr._SHARE = share
@@ -61,7 +62,9 @@ while time.time() < t_end:
     dgr._SHARE = True
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         tag = ("n=%d %dx%d deg %d %s" % (n, W, H, deg, layout), i, float((a - b).abs().max()))
-        if FUSED and i >= 2:
+        if ONES and i == 1:
+            assert float((a - b).abs().max()) <= 3e-6, tag
+        elif FUSED and i >= 2:
             sc = float(b.abs().max())
             if sc == 0:
                 assert float(a.abs().max()) == 0, tag
