@@ -137,7 +137,11 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
  * colors = 1 (gaussian_renderer/__init__.py:121-142).  Given the geom / binning / image state of a
  * previous gs_forward_* call on the SAME means3D, opacities, covariance inputs and camera, this renders
  * new colours (a->shs or a->colors_precomp) without repeating preprocess, sorts and binning: it fills
- * a fresh geom / image state (usable by gs_backward) and shares the binning state. */
+ * a fresh geom / image state (usable by gs_backward) and shares the binning state.  The image is composited from the
+ * quadrant lists the first render recorded (same bits as a stand-alone render); if colors_precomp is all ones -- found
+ * out on the device, one word of geom_src is written -- it is instead written as 1 - T of the first render (+ T bg),
+ * equal to the composited image to fp32 rounding.  Pass the SAME a->long_lists as to the first render.  Its gradients
+ * can be had together with the first render's in one pass: gs_backward_with_second. */
 int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,
                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t num_rendered,
                       float* out_color, void* stream);
