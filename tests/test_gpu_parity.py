@@ -711,6 +711,167 @@ def test_full_size_trained_avatar_shaped_frame_200k_512(oracle, tile_rect):
                     extra_properties=True, layout="body")
 
 
+class _CallCounter(object):
+    """Stands in for the loaded C library and counts the calls per entry point (which backward did the step take?)."""
+
+    def __init__(self, lib):
+        import collections
+        self._lib, self.calls = lib, collections.Counter()
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def counted(*a):
+            self.calls[name] += 1
+            return fn(*a)
+        return counted
+
+
+class _ConvertedCloud(object):
+    """What the reference's render() holds after `scene.convert_gaussians` with its default configuration
+    (gaussian_renderer/__init__.py:73,107-119; configs/config.yaml:89-91): positions, opacities, precomputed 3-D
+    covariances and precomputed colours -- here all four as autograd LEAVES, so that every gradient the rasterizer
+    returns on this input combination can be read off and compared."""
+
+    def __init__(self, cloud, cam, dev):
+        self.xyz = cloud.xyz.to(dev).requires_grad_(True)
+        self.opacity = cloud.opacity.to(dev).requires_grad_(True)
+        self.cov6 = helpers.covariance6_cpu(cloud).to(dev).requires_grad_(True)
+        self.colors = helpers.precomp_colors(cloud, cam).to(dev).requires_grad_(True)
+        self.sh_degree, self.shs, self.scales, self.rotations = cloud.sh_degree, None, None, None
+
+    def covariance6(self, scaling_modifier=1.0):
+        return self.cov6
+
+
+_TWO_CALL_SCENES = {  # name -> (n, W, H, layout, the HIP kernels the frame runs)
+    "config4 200k/512x512": (200000, 512, 512, "box"),     # <= 2048 tiles, no long list: four-wave kernels' one-wave path
+    "avatar 200k/512x512": (200000, 512, 512, "body"),     # lists of thousands: four waves per quadrant, backward in chunks
+    "config3 200k/1024x1024": (200000, 1024, 1024, "box"),  # > 2048 tiles: one wave per quadrant, single walk
+}
+_two_call_oracle = {}
+
+
+def _two_call_reference(oracle, scene, bg):
+    """The oracle's two renders of the reference's step -- colour pass and colours = 1 pass on the same geometry,
+    precomputed colours and covariances -- for one scene and background (kept for the other modes of the same case)."""
+    from simple_knn._C import distCUDA2
+    key = (scene, bg)
+    if key not in _two_call_oracle:
+        dev = torch.device("cuda:0")
+        n, W, H, layout = _TWO_CALL_SCENES[scene]
+        cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, layout=layout,
+                                              dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
+        sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode="precomp", cov_mode="cov")
+        sc1 = helpers.oracle_scene(cloud, cam, bg=bg, color_mode="precomp", colors=torch.ones(n, 3), cov_mode="cov")
+        _two_call_oracle.clear()  # (one scene's state at a time: a forward state is hundreds of megabytes)
+        _two_call_oracle[key] = (cloud, cam, sc, oracle.forward(sc), sc1, oracle.forward(sc1))
+    return _two_call_oracle[key]
+
+
+def _two_call_step(oracle, monkeypatch, scene, bg, mode, use):
+    """The reference's real step at full size against the oracle: `render(cam, pc, Pipe(compute_cov3D_python=True), bg,
+    return_opacity=True)` -- colors_precomp + cov3D_precomp, the colour image and the opacity image
+    (gaussian_renderer/__init__.py:107-142) -- with every switch of the wrapper at its default, a loss on `use` = both
+    images / the opacity image only, and ALL gradient tensors of that input combination compared with
+    oracle.backward(colour pass) + oracle.backward(colours = 1 pass) at the full-size bar.
+
+    mode "second-call": the reference's unmodified two rasterizer calls.  The second one is served from the first one's
+    geometry (gs_forward_shared; colours = 1: second_ones_kernel writes 1 - T) and both images are differentiated by ONE
+    backward pass (gs_backward_with_second: render_bwd_kernel<2>).  mode "with-opacity": one call with with_opacity=True
+    (gs_opacity_image, gs_backward_with_opacity: render_bwd_kernel<1>)."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_mi355 import _lib
+    from gsplat_mi355.render import Pipe, render
+    assert dgr._SHARE and dgr._FUSE_SECOND and dgr._SPECULATE and dgr._LONG_LISTS == "auto"  # the defaults are under test
+    dev = torch.device("cuda:0")
+    n, W, H, layout = _TWO_CALL_SCENES[scene]
+    cloud, cam, sc, fw, sc1, fw1 = _two_call_reference(oracle, scene, bg)
+    gen = torch.Generator().manual_seed(11)
+    g0 = torch.randn(3, H, W, generator=gen)
+    g1 = torch.randn(1, H, W, generator=gen)
+    counter = _CallCounter(_lib.load())
+    monkeypatch.setattr(_lib, "_lib", counter)
+    dgr.release_shared_geometry()
+    hits0 = dgr._geom_cache.hits
+    pc = _ConvertedCloud(cloud, cam, dev)
+    pipe = Pipe(compute_cov3D_python=True, fuse_opacity=(mode == "with-opacity"))
+    pkg = render(cam.to(dev), pc, pipe, torch.tensor(bg, dtype=torch.float32, device=dev), colors_precomp=pc.colors,
+                 return_opacity=True)
+    cam.to("cpu")
+    loss = (pkg.opacity_render * g1.to(dev)).sum()
+    if use == "both":
+        loss = loss + (pkg.render * g0.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    calls = counter.calls
+    if mode == "second-call":
+        assert dgr._geom_cache.hits - hits0 == 1 and calls["gs_forward"] == 1 and calls["gs_forward_shared"] == 1
+        assert calls["gs_backward_with_second"] == 1 and calls["gs_backward"] == 0 and calls["gs_backward_with_opacity"] == 0
+    else:
+        assert calls["gs_forward"] == 1 and calls["gs_forward_shared"] == 0 and calls["gs_opacity_image"] == 1
+        assert calls["gs_backward_with_opacity"] == 1 and calls["gs_backward"] == 0 and calls["gs_backward_with_second"] == 0
+
+    tag = "two-call %s bg=%s %s loss on %s" % (scene, "0" if not any(bg) else "%g,%g,%g" % bg, mode, use)
+    assert np.array_equal(pkg.radii.cpu().numpy(), fw["radii"])
+    color = pkg.render.detach().cpu().numpy()
+    opa = pkg.opacity_render.detach().cpu().numpy()
+    assert opa.shape == (1, H, W)
+    _report(tag, "color", color, fw["color"], extra={"num_rendered": int(fw["binning"]["D"])})
+    _report(tag, "opacity_image", opa[0], fw1["color"][0])
+    _bulk_close(color, fw["color"], name="color " + tag)
+    _bulk_close(opa[0], fw1["color"][0], name="opacity image " + tag)
+    assert np.abs(color - fw["color"]).max() < 1e-2 and np.abs(opa[0] - fw1["color"][0]).max() < 1e-2
+
+    gop = np.zeros((3, H, W), np.float32)
+    gop[0] = g1.numpy()[0]  # the reference keeps channel 0 of the second call's image (`[:1]`)
+    b1 = oracle.backward(sc1, fw1, gop)
+    b0 = oracle.backward(sc, fw, g0.numpy()) if use == "both" else None
+    got = dict(means3D=pc.xyz.grad, means2D=pkg.viewspace_points.grad, opacities=pc.opacity.grad,
+               colors_precomp=pc.colors.grad, cov3D_precomp=pc.cov6.grad)
+    culled = fw["radii"] == 0
+    for k, t in got.items():
+        if k == "colors_precomp":  # (the second call's colours are constants: only the colour pass reaches them)
+            w = b0[k] if b0 is not None else np.zeros((n, 3), np.float32)
+            if t is None:
+                assert b0 is None
+                continue
+        else:
+            w = b1[k].astype(np.float64) + (b0[k] if b0 is not None else 0.0)
+        v = t.cpu().numpy().astype(np.float64)
+        w = np.asarray(w, np.float64).reshape(v.shape)
+        _report(tag, "dL_d" + k, v, w)
+        if np.abs(w).max() == 0:
+            assert (v == 0).all(), k
+            continue
+        _bulk_close(v, w, tol=1e-5, frac=2e-4, name=k + " " + tag, cap=GRAD_CAP)
+        assert (v[culled] == 0).all(), k
+
+
+@pytest.mark.parametrize("scene,bg,mode,use", [
+    ("config4 200k/512x512", (0.0, 0.0, 0.0), "second-call", "both"),
+    ("config4 200k/512x512", (0.0, 0.0, 0.0), "second-call", "opacity"),
+    ("config4 200k/512x512", (0.0, 0.0, 0.0), "with-opacity", "both"),
+    ("config4 200k/512x512", (0.3, 0.6, 0.1), "second-call", "both"),
+    ("config4 200k/512x512", (0.3, 0.6, 0.1), "with-opacity", "both"),
+    ("config4 200k/512x512", (0.3, 0.6, 0.1), "with-opacity", "opacity"),
+    ("avatar 200k/512x512", (0.0, 0.0, 0.0), "second-call", "both"),
+    ("avatar 200k/512x512", (0.0, 0.0, 0.0), "with-opacity", "both"),
+    ("avatar 200k/512x512", (0.3, 0.6, 0.1), "second-call", "both"),
+    ("avatar 200k/512x512", (0.3, 0.6, 0.1), "second-call", "opacity"),
+    ("avatar 200k/512x512", (0.3, 0.6, 0.1), "with-opacity", "both"),
+    ("config3 200k/1024x1024", (0.3, 0.6, 0.1), "second-call", "both"),
+    ("config3 200k/1024x1024", (0.3, 0.6, 0.1), "with-opacity", "both"),
+])
+def test_full_size_reference_step_two_images_default_path(oracle, monkeypatch, scene, bg, mode, use):
+    """The step the reference actually takes (gaussian_renderer/__init__.py:107-142 under
+    configs/config.yaml:73,89-91): precomputed colours + covariances, colour image and opacity image, a loss on both --
+    at config 4's size, on a trained-avatar shaped frame and at config 3's size, black and non-black background, through
+    the wrapper's DEFAULT path (shared geometry, 1 - T image, one backward for both images) and through the fused
+    `with_opacity=True` form; images and all five gradient tensors against the oracle's two passes."""
+    _two_call_step(oracle, monkeypatch, scene, bg, mode, use)
+
+
 def test_heavy_tail_stress_config5_shape(oracle):
     """BASELINE config 5 in miniature: 5 % of the Gaussians with 4x scales (long per-tile lists, many
     64-entry chunks per quadrant), non-zero background, precomputed covariances."""
@@ -1339,8 +1500,9 @@ def test_random_dense_small_scenes_against_oracle(oracle):
 def test_fused_opacity_render_matches_the_second_rasterizer_call(oracle, bgval):
     """N1, second form: rasterizer(..., with_opacity=True) returns the image the reference gets from its second call
     with colours = 1 (`[:1]`, gaussian_renderer/__init__.py:132-142) and its backward returns the SUM of the two calls'
-    gradients -- compared with the two-call path of this library (itself checked against the oracle) and with the
-    oracle's opacity render."""
+    gradients -- compared here with the two-call path of this library and with the oracle's opacity render.  (This is
+    a self-comparison of the gradients; BOTH forms are compared with the oracle's two backward passes, every gradient
+    tensor, in test_full_size_reference_step_two_images_default_path.)"""
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device("cuda:0")
     n, W, H = 3000, 150, 110
