@@ -363,10 +363,20 @@ int launch_opacity_image(const float* final_T, const float* bg, int W, int H, fl
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
                              const GsGrads& g, hipStream_t s);
-// backward scratch: [4 D rows x 32 B: sums 0..7 of (pair, quadrant) at index 4 pair + quadrant, pairs in
+// backward scratch: [4 D rows x 32 B: sums 0..7 of (pair, quadrant) at index gradient_row(...) (below), pairs in
 // emission order (one 32-byte sector per row) | 4 D words: sum 8 of the row, or ROW_UNWRITTEN (the caller
 // fills the array with 0xFF bytes) | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
 #define ROW_UNWRITTEN 0xFFFFFFFFu  // a NaN pattern no arithmetic produces
+// Row of (pair, quadrant): Gaussian i owns the 4 tt rows [4 first_pair, 4 (first_pair + tt)), tt = w h tiles of its
+// rectangle.  QUADRANT-MAJOR inside the span: row = 4 first_pair + q tt + (tile's index in the rectangle, y outer / x
+// inner) -- the four consecutive rows of a 128-byte line are then the SAME quadrant of four x-adjacent tiles, which a
+// Gaussian's footprint reaches together or not at all far more often than the four quadrants of one tile (a footprint
+// is about as large as a tile: most tiles of its rectangle are cut by its boundary), so the rows the backward writes
+// sit in fewer lines for segment_reduce_kernel to fetch.
+__host__ __device__ __forceinline__ uint32_t gradient_row(uint32_t first_pair, uint32_t w, uint32_t h, uint32_t tile_in_rect,
+                                                          uint32_t q) {
+    return first_pair * 4u + q * (w * h) + tile_in_rect;
+}
 static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 32, 256); }
 static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 4, 256); }
 static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }

@@ -11,11 +11,11 @@
 #define GB_THREADS 256  // Gaussians per workgroup of the per-Gaussian backward (its SH tile: 49 floats per Gaussian in LDS)
 #endif
 
-// Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous span of pairs,
-// TWO PAIRS PER STEP -- lane j of the group reads 16 bytes: pair slot j >> 3, quadrant (j >> 1) & 3, half j & 1 of the
-// 32-byte row -- so the eight lanes of a pair read one contiguous 128-byte line (a Gaussian-per-lane-group walk in which
-// every lane fetched whole rows touched 64 different lines per load instruction and ran at half the rate random lines can
-// be read at).  The backward tile kernel wrote only the rows whose ninth sum (the dense word array q8) is not
+// Segmented sum of the per-(pair, quadrant) gradient rows: 16 lanes per Gaussian walk its contiguous span of 4 tt rows
+// (common.h: gradient_row), EIGHT ROWS PER STEP -- lane j of the group reads 16 bytes: row j >> 1 of the step, half j & 1
+// of the 32-byte row -- so the lanes of a group read 256 contiguous bytes (a Gaussian-per-lane-group walk in which every
+// lane fetched whole rows touched 64 different lines per load instruction and ran at half the rate random lines can be
+// read at).  The backward tile kernel wrote only the rows whose ninth sum (the dense word array q8) is not
 // ROW_UNWRITTEN.  Fold with DPP adds.
 // sums[i] = 12 floats.
 __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_t* __restrict__ radii,
@@ -26,35 +26,41 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
                                                              float4* __restrict__ sums) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t >> 4, j = t & 15;
-    const int ps = j >> 3, q = (j >> 1) & 3, h = j & 1;
+    const int rs = j >> 1, h = j & 1;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a8 = 0.f;
     const bool in = i < P;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
     if (in && radii[i] > 0) {
         const uint32_t off = __float_as_uint(rec[(size_t)i * 3 + 2].y);
-        const uint32_t tt = tiles[i];
+        const uint32_t nrows = 4u * tiles[i];
+        if (j < 2) {  // (what the last step needs of the record: requested now, not behind the rows)
+            r0 = rec[(size_t)i * 3];
+            r1 = rec[(size_t)i * 3 + 1];
+        }
+        const size_t row0 = (size_t)off * 4;
         // The kernel is a chain of dependent load latencies (record -> marks -> rows) times the number of wave generations,
-        // not bandwidth: a trip covers 16 pairs of the Gaussian (8 per lane: most Gaussians need one trip), all marks of a
-        // trip are requested together, then all its rows, and the next trip's marks are requested before this trip's rows
-        // are added up.
+        // not bandwidth: a trip covers 64 rows of the Gaussian (8 per lane: most Gaussians need one or two trips), all marks
+        // of a trip are requested together, then all its rows, and the next trip's marks are requested before this trip's
+        // rows are added up.
         constexpr int U = 8;
         uint32_t mark[U], mark_n[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t k = (uint32_t)ps + 2u * u;
-            mark[u] = k < tt ? q8[(size_t)(off + k) * 4 + q] : ROW_UNWRITTEN;
+            const uint32_t k = (uint32_t)rs + 8u * u;
+            mark[u] = k < nrows ? q8[row0 + k] : ROW_UNWRITTEN;
         }
-        for (uint32_t k0 = (uint32_t)ps; k0 < tt; k0 += 2u * U) {
+        for (uint32_t k0 = (uint32_t)rs; k0 < nrows; k0 += 8u * U) {
             float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t k = k0 + 2u * u;
+                const uint32_t k = k0 + 8u * u;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mark[u] != ROW_UNWRITTEN) v[u] = qrows[((size_t)(off + k) * 4 + q) * 2 + h];
+                if (mark[u] != ROW_UNWRITTEN) v[u] = qrows[(row0 + k) * 2 + h];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t k = k0 + 2u * U + 2u * u;
-                mark_n[u] = k < tt ? q8[(size_t)(off + k) * 4 + q] : ROW_UNWRITTEN;
+                const uint32_t k = k0 + 8u * U + 8u * u;
+                mark_n[u] = k < nrows ? q8[row0 + k] : ROW_UNWRITTEN;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -64,8 +70,8 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
             }
         }
     }
-    // fold the two pair slots (lane ^ 8) and the four quadrants (lane ^ 2, lane ^ 4): lanes with h = 0 end up with the
-    // sums 0..3 and 8, lanes with h = 1 with the sums 4..7
+    // fold the eight row slots (lane ^ 2, lane ^ 4, lane ^ 8): lanes with h = 0 end up with the sums 0..3 and 8, lanes
+    // with h = 1 with the sums 4..7
     float f[5] = {a0, a1, a2, a3, a8};
 #pragma unroll
     for (int c = 0; c < 5; c++) {
@@ -80,7 +86,6 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
     // conic combination giving dL/dmean2D (in the log2 domain the tile kernels work in), and the -1/2 of
     // dL/dconic.
     if (in && j < 2) {
-        const float4 r0 = rec[(size_t)i * 3], r1 = rec[(size_t)i * 3 + 1];
         const float A2 = (-0.5f * LOG2E_F) * r0.z, B2 = -LOG2E_F * r0.w, C2 = (-0.5f * LOG2E_F) * r1.x, op = r1.y;
         const float il2 = 1.0f / LOG2E_F;
         if (j == 0) {

@@ -30,7 +30,7 @@
 //        dL/dalpha_i = T_i (c_i . g) - Rem_i / (1 - alpha_i)
 //    which is the reference's back-to-front recurrence (accum_rec / T division) rewritten so that T is
 //    rebuilt by the same multiplications the forward did.
-//  * Output: the nine raw sums of (pair, quadrant) at row 4 pair + quadrant, pairs in EMISSION order
+//  * Output: the nine raw sums of (pair, quadrant) at row gradient_row(...) (common.h), pairs in EMISSION order
 //    (Gaussian-major), so the per-Gaussian kernel reads one contiguous span per Gaussian: eight sums in
 //    a 32-byte row, the ninth in a dense word array the caller pre-fills with ROW_UNWRITTEN, so it also
 //    tells which rows were written.
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         gtot0 = c0.w;
     }
 
-    // record (p0,p1,p2) -> the loop's entry form + the row index 4 pair + quadrant
+    // record (p0,p1,p2) -> the loop's entry form + the gradient row of (pair, quadrant)
     auto convert = [&](const float4 p0, const float4 p1, const float4 p2, Entry& e, uint32_t& row) {
         e.x = p0.x; e.y = p0.y;
         e.A2 = (-0.5f * LOG2E_F) * p0.z;
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         e.C2 = (-0.5f * LOG2E_F) * p1.x;
         e.o = p1.y; e.r = p1.z; e.g = p1.w; e.b = p2.x;
         const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
-        const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
-        row = (off + ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx)) * 4u + (uint32_t)q;
+        const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu, h = rsz >> 16;
+        row = gradient_row(off, w, h, ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx), (uint32_t)q);
     };
     float3 q2 = make_float3(0.f, 0.f, 0.f);  // (SECOND) the gathered entry's colour in the second image
     auto gather = [&](int k, float4& p0, float4& p1, float4& p2) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
     Entry cur = {}, nxt = {};
-    uint32_t nxt_row = 0;  // gradient row (4 pair + quadrant) of the entry in `nxt`
+    uint32_t nxt_row = 0;  // gradient row of the entry in `nxt`
     gather(j, p0, p1, p2);              // (the four rings hold the same entries)
     convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by position t of every ring at step t
     convert2(nxt);
