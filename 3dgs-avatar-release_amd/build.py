@@ -11,8 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT_DIR = os.path.join(HERE, "lib")
-OBJ_DIR = os.path.join(HERE, "build")
+# GSPLAT_VARIANT=name: an experimental build next to the product one (variants/name/, with GSPLAT_EXTRA_HIPCC_FLAGS;
+# loaded through GSPLAT_LIB_PATH) -- the product library is lib/libgsplat_mi355.so
+_VARIANT = os.environ.get("GSPLAT_VARIANT")
+OUT_DIR = os.path.join(HERE, "..", "variants", _VARIANT) if _VARIANT else os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(OUT_DIR, "obj") if _VARIANT else os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libgsplat_mi355.so")
 
 ARCH = "gfx950"

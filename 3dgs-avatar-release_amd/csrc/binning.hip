@@ -191,7 +191,8 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
 __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist,
                                                                  const uint32_t* __restrict__ chunk_pairs, int P, int gx,
                                                                  int gy, int band_rows, int nbands, int nseg, int ntiles,
-                                                                 uint32_t* __restrict__ seg_cnt) {
+                                                                 uint32_t* __restrict__ seg_cnt,
+                                                                 uint32_t* __restrict__ tile_tot) {
     __shared__ int grid[TC_CELLS];
     __shared__ unsigned long long sb_scratch[20];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -243,10 +244,150 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
                 const int t = __shfl_up(s, d, 64);
                 if (lane >= d) s += t;
             }
-            if (x < gx) seg_cnt[(size_t)sg * ntiles + (size_t)(y0b + y) * gx + x] = (uint32_t)(carry + s);
+            const uint32_t c = x < gx ? (uint32_t)(carry + s) : 0u;
+            const int t0 = (y0b + y) * gx + x0;  // lane 0's tile (wave-uniform)
+            if (x < gx) seg_cnt[(size_t)sg * ntiles + (size_t)(t0 + lane)] = c;
+            // the tile's pairs over all segments: integer atomics into words an earlier kernel of the frame cleared (one
+            // 256-byte atomic instruction per wave and trip; measured free next to the kernel's 12 us.  Sums per group of
+            // tiles added the same way by one lane cost 6 us: 48 workgroups hitting the same word at the same moment)
+            if (c) atomicAdd(&tile_tot[t0 + lane], c);
             carry += __shfl(s, 63, 64);
         }
     }
+}
+
+// Launch order of the per-tile render waves: tiles sorted by DESCENDING work estimate (a counting
+// sort into 1024 bins of work / max_work; ties in any order).  All tile waves of a frame are
+// resident at once and the hardware deals workgroups breadth-first over the SIMDs, so handing out
+// the tiles heaviest-first gives every SIMD one tile from each work quantile -- the kernel then
+// ends with its SIMDs finishing together instead of on the few that drew several centre tiles.
+// mode 0: work = list length (ranges), mode 1: work = sum of keys[4 tile .. 4 tile + 3] (the forward's
+// per-quadrant last contributor), mode 2: work = keys[tile] = the tile's pair count (tile_count_kernel).
+__device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
+                                              int t) {
+    if (mode == 2) return keys[t];
+    return mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
+}
+// One workgroup of 1024 threads.  HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the
+// inputs are loaded once, all loads in flight together (ntiles <= 32 * 1024); otherwise the phases re-read them.
+// LDS: hist[1024], wmax[16], wsum[16].
+template <bool HELD>
+__device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
+                                                int ntiles, uint32_t* __restrict__ order, const PairCount pc,
+                                                const LongLists ll, uint32_t* hist, uint32_t* wmax, uint32_t* wsum) {
+    constexpr int PER = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    hist[tid] = 0;
+    uint32_t held[HELD ? PER : 1];
+    uint32_t mx = 0;
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;  // workgroup-uniform
+            const int t = i * 1024 + tid;
+            held[i] = t < ntiles ? tile_work(ranges, keys, mode, t) : 0u;
+            mx = max(mx, held[i]);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) wmax[wid] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
+    const float scale = mx ? 1023.0f / (float)mx : 0.f;
+    auto bin_of = [&](uint32_t w) { return 1023u - min(1023u, (uint32_t)((float)w * scale)); };
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            if (i * 1024 + tid < ntiles) atomicAdd(&hist[bin_of(held[i])], 1u);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins
+    const uint32_t v = hist[tid];
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    hist[tid] = woff + x - v;
+    __syncthreads();
+    // Small images (mark_wide, forward only): a tile whose list is long against the frame's total keeps a quadrant wave
+    // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
+    // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
+    uint32_t wide_from = 0xFFFFFFFFu;
+    if (mode == 2) {
+        const unsigned long long D = *pc.dev;
+        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
+        if (ll.stats) {
+            // how many such tiles, and the longest list (GsFwdArgs.frame_stats: diagnostics)
+            uint32_t nlong = 0;
+            if (HELD) {
+#pragma unroll
+                for (int i = 0; i < PER; i++) {
+                    if (i * 1024 >= ntiles) break;
+                    nlong += (i * 1024 + tid < ntiles && held[i] > wide_from) ? 1u : 0u;
+                }
+            } else {
+                for (int t = tid; t < ntiles; t += 1024) nlong += tile_work(ranges, keys, mode, t) > wide_from ? 1u : 0u;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nlong += (uint32_t)__shfl_xor((int)nlong, d, 64);
+            __syncthreads();  // (wsum is free again: the scan above has read it)
+            if (lane == 0) wsum[wid] = nlong;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < 16; w++) tot += wsum[w];
+                __hip_atomic_store(&ll.stats[0], (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&ll.stats[1], (long long)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        if (!ll.mark) wide_from = 0xFFFFFFFFu;
+    }
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            const int t = i * 1024 + tid;
+            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t | (held[i] > wide_from ? 0x80000000u : 0u);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) {
+            const uint32_t wk = tile_work(ranges, keys, mode, t);
+            order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (wk > wide_from ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// The ordering as a launch of its own (the backward: mode 1; an empty frame: mode 0).  Its other workgroups do a side
+// job (see FillJob).
+template <bool HELD>
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ keys, int mode, int ntiles,
+                                                          uint32_t* __restrict__ order, const PairCount pc,
+                                                          const FillJob fill, const LongLists ll) {
+    if (blockIdx.x > 0) {  // the side job; workgroup 0 does the ordering
+        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
+            if (fill.stream) store_stream(&fill.ptr[k], ones); else fill.ptr[k] = ones;
+        return;
+    }
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t wsum[16];
+    tile_order_body<HELD>(ranges, keys, mode, ntiles, order, pc, ll, hist, wmax, wsum);
 }
 
 // ---- writing pass.  Workgroup (block of 64 x 4 tiles, segment).  The kernel's arithmetic is trivial; what it is built
@@ -258,25 +399,89 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
                                                                  const uint32_t* __restrict__ chunk_pairs, int P, int gx,
                                                                  int gy, int nbx, int nblocks, int nseg, int ntiles,
                                                                  const uint32_t* __restrict__ seg_cnt,
-                                                                 const uint2* __restrict__ ranges,
-                                                                 uint32_t* __restrict__ point_list, const PairCount pc) {
+                                                                 const uint32_t* __restrict__ tile_tot,
+                                                                 uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                                 uint32_t* __restrict__ point_list, const PairCount pc,
+                                                                 const LongLists ll) {
     __shared__ uint32_t m_id[TBK_BUF];
     __shared__ unsigned short m_rc[TBK_BUF];
     __shared__ uint32_t bitmap[TB_TILES * BM_LD];  // [local tile][word]: bit m = "Gaussian m of the batch covers the tile"
     __shared__ uint32_t dst[TB_TILES];             // next free slot of every tile's list for this workgroup
     __shared__ uint32_t wcnt[TBK_WAVES];
     __shared__ unsigned long long sb_scratch[20];
+    static_assert(TBK_THREADS == 1024 && TBK_WAVES == 16 && TB_H <= 4 && TB_TILES * BM_LD >= 1024 && TB_TILES >= 32, "the ordering job borrows bitmap / dst");
+    if (blockIdx.x == 0) {
+        // Workgroup 0: the launch order of the render kernel's tile waves (heaviest first) from the tiles' pair counts --
+        // nothing in this launch needs it, so it rides along instead of being a launch of one workgroup
+        if (ntiles <= 32 * 1024) tile_order_body<true>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        else tile_order_body<false>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int b = (int)blockIdx.x % nblocks, sg = (int)blockIdx.x / nblocks;
+    const int b = ((int)blockIdx.x - 1) % nblocks, sg = ((int)blockIdx.x - 1) / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
-    // the list bases and the pair count are requested before the segment's rank range is worked out
-    uint32_t my_dst = 0;
-    if (tid < TB_TILES) {
-        const int tx = bx0 + (tid & (TB_W - 1)), ty = by0 + (tid >> 6);
-        if (tx < bx1 && ty < by1) my_dst = ranges[ty * gx + tx].x + seg_cnt[(size_t)sg * ntiles + ty * gx + tx];
-    }
     const unsigned long long frame_pairs = *pc.dev;
+    // If the frame's pair count does not fit the state the lists were carved for, every range is left empty: the render
+    // that follows then draws an empty frame and touches nothing out of bounds (the host runs the phase again).
+    const bool fits = frame_pairs <= (unsigned long long)pc.cap;
+    // Tile ranges (upstream identifyTileRanges) and this workgroup's first slot in every list, from the counting pass:
+    // first pair of tile t = pairs of all tiles before it (tile_tot) + the pairs the earlier segments put into t (seg_cnt).
+    // All threads add up the tiles before the block's first row; wave r takes row r of the block -- 64 consecutive tiles,
+    // whose prefix is one wave scan -- and the tiles from its row's start to the next row's.  All loads are independent:
+    // one trip to the L2, one barrier.
+    uint32_t my_dst = 0;
+    {
+        const int t_blk0 = by0 * gx + bx0;
+        uint32_t part = 0;
+        for (int t = tid; t < t_blk0; t += TBK_THREADS) part += tile_tot[t];
+        const int ty = by0 + wid, tx = bx0 + lane;
+        const bool row_ok = tid < TB_TILES && ty < by1;  // (wave-uniform)
+        const int t_row0 = ty * gx + bx0, t = t_row0 + lane;
+        const bool tile_ok = row_ok && tx < bx1;
+        uint32_t tot = 0, pre = 0, rowsum = 0;
+        if (row_ok) {
+            // (linear tile order: wraps into the next tile row; only rows that have a row behind them in the block are used)
+            for (int k = lane; k < gx; k += 64) rowsum += t_row0 + k < ntiles ? tile_tot[t_row0 + k] : 0u;
+            if (tile_ok) {
+                tot = tile_tot[t];
+                for (int s0 = 0; s0 < sg; s0 += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = (s0 + k < sg) ? seg_cnt[(size_t)(s0 + k) * ntiles + t] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) pre += v[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            part += __shfl_xor(part, d, 64);
+            rowsum += __shfl_xor(rowsum, d, 64);
+        }
+        uint32_t* s_part = reinterpret_cast<uint32_t*>(sb_scratch);  // 16 partial sums + 4 row sums (free until segment_bounds)
+        if (lane == 0) {
+            s_part[wid] = part;
+            if (wid < TB_H) s_part[16 + wid] = rowsum;
+        }
+        __syncthreads();
+        if (row_ok) {
+            uint32_t before = 0;
+            for (int w = 0; w < TBK_WAVES; w++) before += s_part[w];
+            for (int r = 0; r < wid; r++) before += s_part[16 + r];
+            uint32_t x = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            const uint32_t first = before + x - tot;
+            if (sg == 0 && tile_ok) ranges[t] = fits ? make_uint2(first, first + tot) : make_uint2(0u, 0u);
+            my_dst = first + pre;
+        }
+        __syncthreads();  // (sb_scratch is segment_bounds' from here on)
+    }
+    if (!fits || !point_list) return;  // (workgroup-uniform) the host sees the count and runs the phase again, larger state
     for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
     int r0, r1;
     segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
@@ -289,8 +494,6 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         }
     };
     load_trip(r0);
-    if (frame_pairs > (unsigned long long)pc.cap) return;  // the lists would not fit the state they were carved for: the host
-                                                           // sees the count and runs the phase again (workgroup-uniform)
     if (tid < TB_TILES) dst[tid] = my_dst;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int count = 0;  // compacted Gaussians in the buffer (workgroup-uniform)
@@ -414,229 +617,36 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     }
 }
 
-// One wave per group of 64 tiles.  Per tile: the segments' pair counts -> their exclusive prefix (in place; all loads of
-// a tile in flight together) and the tile's total; per group: the tiles' exclusive prefix inside the group and the
-// group's total, from which one workgroup finishes the tile ranges (tile_order_kernel, mode 2).
-__global__ __launch_bounds__(64) void seg_prefix_kernel(uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ tile_tot,
-                                                        uint32_t* __restrict__ tile_loc, uint32_t* __restrict__ grp_sum,
-                                                        int ntiles, int nseg) {
-    const int lane = threadIdx.x;
-    const int t = blockIdx.x * 64 + lane;
-    uint32_t acc = 0;
-    if (t < ntiles) {
-        for (int g0 = 0; g0 < nseg; g0 += 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = (g0 + k < nseg) ? seg_cnt[(size_t)(g0 + k) * ntiles + t] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (g0 + k < nseg) seg_cnt[(size_t)(g0 + k) * ntiles + t] = acc;
-                acc += v[k];
-            }
-        }
-        tile_tot[t] = acc;
-    }
-    uint32_t x = acc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (t < ntiles) tile_loc[t] = x - acc;
-    if (lane == 63) grp_sum[blockIdx.x] = x;
-}
-
-// Launch order of the per-tile render waves: tiles sorted by DESCENDING work estimate (a counting
-// sort into 1024 bins of work / max_work; ties in any order).  All tile waves of a frame are
-// resident at once and the hardware deals workgroups breadth-first over the SIMDs, so handing out
-// the tiles heaviest-first gives every SIMD one tile from each work quantile -- the kernel then
-// ends with its SIMDs finishing together instead of on the few that drew several centre tiles.
-// mode 0: work = list length (ranges), mode 1: work = sum of keys[4 tile .. 4 tile + 3] (the forward's
-// per-quadrant last contributor).
-__device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
-                                              int t) {
-    if (mode == 2) return keys[t];
-    return mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
-}
-// mode 2: work = keys[tile] = the tile's pair count (seg_prefix_kernel); the kernel then FIRST writes the tile ranges
-// (exclusive prefix sum of the counts: upstream identifyTileRanges) into `ranges_out`.
-// HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the inputs are loaded once, all
-// loads in flight together (ntiles <= 32 * 1024); otherwise the three phases re-read them.
-template <bool HELD>
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ keys, int mode, int ntiles,
-                                                          uint32_t* __restrict__ order, uint2* __restrict__ ranges_out,
-                                                          const uint32_t* __restrict__ loc,
-                                                          const uint32_t* __restrict__ grp, const PairCount pc,
-                                                          const FillJob fill, const LongLists ll) {
-    if (blockIdx.x > 0) {  // the side job (see FillJob); workgroup 0 does the ordering
-        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
-            if (fill.stream) store_stream(&fill.ptr[k], ones); else fill.ptr[k] = ones;
-        return;
-    }
-    constexpr int PER = 32;
-    __shared__ uint32_t hist[1024];
-    __shared__ uint32_t wmax[16];
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    hist[tid] = 0;
-    if (tid == 0) carry_s = 0;
-    uint32_t held[HELD ? PER : 1];
-    uint32_t mx = 0;
-    if (HELD) {
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (i * 1024 >= ntiles) break;  // workgroup-uniform
-            const int t = i * 1024 + tid;
-            held[i] = t < ntiles ? tile_work(ranges, keys, mode, t) : 0u;
-            mx = max(mx, held[i]);
-        }
-    } else {
-        for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
-    }
-    if (mode == 2) {
-        // tile ranges (upstream identifyTileRanges): first pair of tile t = pairs of the 64-tile groups before its own
-        // (scanned here, 1024 groups per trip) + its prefix inside the group (seg_prefix_kernel).  If the frame's pair
-        // count does not fit the state the lists were carved for, every range is left empty: the render that follows
-        // then draws an empty frame and touches nothing out of bounds (the host runs the phase again, larger state).
-        const bool fits = *pc.dev <= (unsigned long long)pc.cap;
-        const int ngrp = (ntiles + 63) / 64;
-        __syncthreads();
-        for (int g0 = 0; g0 < ngrp; g0 += 1024) {
-            const int g = g0 + tid;
-            const uint32_t v = g < ngrp ? grp[g] : 0u;
-            uint32_t x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= d) x += y;
-            }
-            if (lane == 63) wsum[wid] = x;
-            __syncthreads();
-            uint32_t woff = 0, tot = 0;
-            for (int w = 0; w < 16; w++) {
-                const uint32_t c = wsum[w];
-                woff += w < wid ? c : 0u;
-                tot += c;
-            }
-            hist[tid] = carry_s + woff + x - v;  // first pair of group g (hist is free until the ordering below)
-            __syncthreads();
-            const int t1 = min(ntiles, (g0 + 1024) * 64);
-            for (int t = g0 * 64 + tid; t < t1; t += 1024) {
-                const uint32_t first = hist[(t >> 6) - g0] + loc[t], n = keys[t];
-                ranges_out[t] = fits ? make_uint2(first, first + n) : make_uint2(0u, 0u);
-            }
-            if (tid == 0) carry_s += tot;
-            __syncthreads();
-        }
-        hist[tid] = 0;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if (lane == 0) wmax[wid] = mx;
-    __syncthreads();
-    mx = 0;
-    for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
-    const float scale = mx ? 1023.0f / (float)mx : 0.f;
-    auto bin_of = [&](uint32_t w) { return 1023u - min(1023u, (uint32_t)((float)w * scale)); };
-    if (HELD) {
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (i * 1024 >= ntiles) break;
-            if (i * 1024 + tid < ntiles) atomicAdd(&hist[bin_of(held[i])], 1u);
-        }
-    } else {
-        for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the 1024 bins
-    const uint32_t v = hist[tid];
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; w++) woff += wsum[w];
-    hist[tid] = woff + x - v;
-    __syncthreads();
-    // Small images (mark_wide, forward only): a tile whose list is long against the frame's total keeps a quadrant wave
-    // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
-    // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
-    uint32_t wide_from = 0xFFFFFFFFu;
-    if (mode == 2) {
-        const unsigned long long D = *pc.dev;
-        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
-        if (ll.stats) {
-            // how many such tiles, and the longest list: for the caller's choice of GsFwdArgs.long_lists next frame
-            uint32_t nlong = 0;
-            if (HELD) {
-#pragma unroll
-                for (int i = 0; i < PER; i++) {
-                    if (i * 1024 >= ntiles) break;
-                    nlong += (i * 1024 + tid < ntiles && held[i] > wide_from) ? 1u : 0u;
-                }
-            } else {
-                for (int t = tid; t < ntiles; t += 1024) nlong += tile_work(ranges, keys, mode, t) > wide_from ? 1u : 0u;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) nlong += (uint32_t)__shfl_xor((int)nlong, d, 64);
-            __syncthreads();  // (wsum is free again: the scan above has read it)
-            if (lane == 0) wsum[wid] = nlong;
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t tot = 0;
-                for (int w = 0; w < 16; w++) tot += wsum[w];
-                __hip_atomic_store(&ll.stats[0], (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&ll.stats[1], (long long)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        if (!ll.mark) wide_from = 0xFFFFFFFFu;
-    }
-    if (HELD) {
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (i * 1024 >= ntiles) break;
-            const int t = i * 1024 + tid;
-            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t | (held[i] > wide_from ? 0x80000000u : 0u);
-        }
-    } else {
-        for (int t = tid; t < ntiles; t += 1024) {
-            const uint32_t wk = tile_work(ranges, keys, mode, t);
-            order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (wk > wide_from ? 0x80000000u : 0u);
-        }
-    }
-}
-
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, uint32_t* ranges_out,
-                      const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, LongLists ll, int debug,
-                      hipStream_t s) {
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, PairCount pc,
+                      FillJob fill, LongLists ll, int debug, hipStream_t s) {
     // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
     const size_t pieces = (fill.quads + 1023) / 1024;
     const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, ll);
+                           keys, mode, ntiles, order, pc, fill, ll);
     else
         hipLaunchKernelGGL(tile_order_kernel<false>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
-                           keys, mode, ntiles, order, reinterpret_cast<uint2*>(ranges_out), loc, grp, pc, fill, ll);
+                           keys, mode, ntiles, order, pc, fill, ll);
     GS_LAUNCH_CHECK("tile_order", debug, s);
     return GS_OK;
 }
 
-// The whole tile binning of one frame: counting pass, prefixes, ranges + launch order, writing pass.
+// The whole tile binning of one frame: counting pass (per-(segment, tile) counts, per-tile totals), then the writing pass,
+// whose workgroups derive the tile ranges and their list slots from the counts themselves and whose first workgroup
+// orders the tiles for the render launch.  `totals_zeroed`: tc.tile_tot .. (tc.zero_bytes) were cleared by an earlier
+// kernel of this frame (the preprocess kernel); otherwise they are cleared here.
 int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, int debug, hipStream_t s) {
+                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, bool totals_zeroed, int debug,
+                      hipStream_t s) {
     uint32_t* seg_cnt = tc.seg_cnt;
     const BinGrid G = bin_grid(gx, gy);
     const int nseg = bin_segments(G, P);  // segments of about equal work (segment_bounds)
     const int ntiles = gx * gy;
-    const dim3 grid((unsigned)(G.nblocks * nseg));
+    if (!totals_zeroed) {
+        hipError_t e = hipMemsetAsync(tc.tile_tot, 0, tc.zero_bytes, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "tile_totals.memset"); return GS_E_HIP; }
+    }
     {
         // counting pass: bands of tile rows that fit the LDS grid (the whole tile grid up to ~110 x 110 tiles)
         int band_rows = TC_CELLS / (gx + 1) - 1;
@@ -645,21 +655,14 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P,
         const int nbands = (gy + band_rows - 1) / band_rows;
         StageScope sc_("tile_count", s);
         hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, s, ranklist, chunk_pairs, P,
-                           gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt);
+                           gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt, tc.tile_tot);
         GS_LAUNCH_CHECK("tile_count", debug, s);
     }
-    { StageScope sc_("seg_prefix", s);
-    hipLaunchKernelGGL(seg_prefix_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, s, seg_cnt, tc.tile_tot, tc.tile_loc, tc.grp_sum,
-                       ntiles, nseg);
-    GS_LAUNCH_CHECK("seg_prefix", debug, s); }
-    { StageScope sc_("ranges_order", s);
-    const int rc = launch_tile_order(nullptr, tc.tile_tot, 2, ntiles, order, ranges, tc.tile_loc, tc.grp_sum, pc,
-                                     FillJob{nullptr, 0}, ll, debug, s);
-    if (rc != GS_OK) return rc; }
-    if (pc.cap > 0) {
+    {
         StageScope sc_("tile_write", s);
-        hipLaunchKernelGGL(tile_write_kernel, grid, dim3(TBK_THREADS), 0, s, ranklist, chunk_pairs, P, gx, gy, G.nbx, G.nblocks,
-                           nseg, ntiles, seg_cnt, reinterpret_cast<const uint2*>(ranges), point_list, pc);
+        hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, s, ranklist,
+                           chunk_pairs, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
+                           reinterpret_cast<uint2*>(ranges), order, pc.cap > 0 ? point_list : nullptr, pc, ll);
         GS_LAUNCH_CHECK("tile_write", debug, s);
     }
     return GS_OK;

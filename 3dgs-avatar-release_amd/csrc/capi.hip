@@ -141,10 +141,12 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         uint32_t* v1 = (uint32_t*)(g + L.val1);
         ZeroJob zt;  // the depth sort's digit totals, cleared by the preprocess kernel
         sort_totals_region((uint32_t*)(g + L.hist), a->P, 32, &zt.ptr, &zt.words);
+        // ... and the image state's per-tile pair totals, which phase 2's counting pass adds into
+        const ZeroJob zi{(uint32_t*)((char*)img + I.tile_tot), (int)(I.tile_zero_bytes / 4)};
         { StageScope sc_("preprocess", s);
         rc = launch_preprocess(*a, (float*)(g + L.rec), (float*)(g + L.depths), (uint32_t*)(g + L.tiles),
                                (uint32_t*)(g + L.clamped), k0, v0, radii, (uint32_t*)(g + L.wsum), (uint32_t*)(g + L.wkmin),
-                               (uint32_t*)(g + L.wkmax), zt, s); }
+                               (uint32_t*)(g + L.wkmax), zt, zi, s); }
         if (rc != GS_OK) return rc;
         // pair numbering (Gaussian-major, index order) and the pair count need nothing of the depth sort, so the count is
         // on its way to the host while the sort runs; (depth key, index) order: ties keep ascending Gaussian index (the
@@ -191,8 +193,9 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 // Phase 2 against a binning state carved for `cap` pairs.  The kernels read the frame's pair count from the geom state
 // on the device (PairCount): the phase can be enqueued before the host knows the count; a count beyond `cap` makes every
 // kernel do the work of an empty frame (nothing out of bounds) and the caller runs the phase again with a larger state.
+// `totals_zeroed`: phase 1 has just run on this image state (its preprocess kernel cleared the per-tile pair totals).
 static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
-                          size_t img_bytes, int64_t cap, float* out_color, void* stream) {
+                          size_t img_bytes, int64_t cap, float* out_color, void* stream, bool totals_zeroed) {
     if (!geom || !img || !out_color || cap < 0 || (cap > 0 && !binning)) return GS_E_BAD_ARG;
     if (cap > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const GeomLayout L = geom_layout(a->P);
@@ -213,18 +216,18 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     if (a->P > 0) {
         point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
         rc = launch_tile_lists((const uint4*)(g + L.ranklist), (const uint32_t*)(g + L.chunk_pairs), a->P, I.gx, I.gy,
-                               TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), (uint32_t*)(im + I.tile_loc),
-                                          (uint32_t*)(im + I.grp_sum)},
+                               TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), I.tile_zero_bytes},
                                ranges, (uint32_t*)(im + I.order),
                                cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc,
-                               LongLists{forward_small_image(ntiles, a->long_lists) ? 1 : 0, (long long*)a->frame_stats}, a->debug, s);
+                               LongLists{forward_small_image(ntiles, a->long_lists) ? 1 : 0, (long long*)a->frame_stats},
+                               totals_zeroed, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
         hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
         if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
         StageScope sc_("ranges_order", s);
-        rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), nullptr, nullptr, nullptr, pc,
-                               FillJob{nullptr, 0}, LongLists{0, nullptr}, a->debug, s);
+        rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), pc, FillJob{nullptr, 0},
+                               LongLists{0, nullptr}, a->debug, s);
         if (rc != GS_OK) return rc;
     }
     QuadLists ql;
@@ -250,7 +253,7 @@ int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* b
                       void* img, size_t img_bytes, int64_t D, float* out_color, void* stream) {
     int rc = validate(a);
     if (rc != GS_OK) return rc;
-    return forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream);
+    return forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream, false);
 }
 
 // Both phases in one call, WITHOUT a GPU idle stretch for the pair count.  The binning state the caller passes was
@@ -274,7 +277,7 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
     if (rc != GS_OK) return rc;
     const bool speculate = capacity > 0 && binning && binning_bytes >= bin_layout(capacity).total && capacity <= GS_MAX_PAIRS;
     if (speculate) {
-        rc = forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, capacity, out_color, stream);
+        rc = forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, capacity, out_color, stream, true);
         if (rc != GS_OK) return rc;
     }
     bool have = false;
@@ -415,9 +418,9 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, nullptr, nullptr, nullptr,
-                               PairCount{nullptr, 0}, FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1}, LongLists{0, nullptr},
-                               a->debug, s); }
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, PairCount{nullptr, 0},
+                               FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1},
+                               LongLists{0, nullptr}, a->debug, s); }
         if (rc != GS_OK) return rc;
         SecondImage si{nullptr, nullptr, nullptr, nullptr};
         if (second) {

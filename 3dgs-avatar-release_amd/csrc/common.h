@@ -140,7 +140,7 @@ int gs_tune_get(int key);
 #endif
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_loc, grp_sum, ckpt, ck_start, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_zero_bytes, ckpt, ck_start, total;
     int gx, gy, bwd_chunks;
 };
 // `long_lists`: GsFwdArgs.long_lists (the few-long-lists machinery on an image of any size)
@@ -160,10 +160,9 @@ static inline ImgLayout img_layout(int W, int H, int long_lists = 0) {
     L.ncon_c = take((size_t)W * H * 4);            // per pixel: last contributor in its quadrant's COMPACTED list
     L.tile_nmax = take(nt * 16);                   // per quadrant: compacted entries up to the last contributor
     L.order = take(nt * 4);
-    L.seg_cnt = take(nt * 4 * (size_t)bin_grid(L.gx, L.gy).nseg_max);  // [segment][tile] pair counts, then their prefix
+    L.seg_cnt = take(nt * 4 * (size_t)bin_grid(L.gx, L.gy).nseg_max);  // [segment][tile] pair counts
     L.tile_tot = take(nt * 4);                     // pairs per tile
-    L.tile_loc = take(nt * 4);                     // ... and their exclusive prefix inside the tile's group of 64 tiles
-    L.grp_sum = take((nt / 64 + 1) * 4);           // pairs per group of 64 tiles
+    L.tile_zero_bytes = nt * 4;
     L.bwd_chunks = few_long_lists_mode((int)nt, long_lists) ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
@@ -235,7 +234,7 @@ struct StageScope {
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
-                      uint32_t* wave_kmax, ZeroJob zero, hipStream_t s);
+                      uint32_t* wave_kmax, ZeroJob zero, ZeroJob zero2, hipStream_t s);
 // bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
 struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range; int nb, blocks; };
 // pair numbering done by the sort's first launch (see first_pair_kernel, which the radix path uses) and the rank list
@@ -271,12 +270,15 @@ int launch_first_pair(const uint32_t* tiles, const uint32_t* wave_tiles, float* 
 // tile binning (binning.hip): rank list -> per-(segment, tile) counts -> ranges + launch order -> tile lists
 int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_t* tiles, uint4* ranklist,
                      uint32_t* chunk_pairs, int P, int debug, hipStream_t s);
-struct TileCounts { uint32_t *seg_cnt, *tile_tot, *tile_loc, *grp_sum; };
+// per-(segment, tile) pair counts; per-tile totals (integer atomics of the counting pass into words cleared beforehand:
+// `zero_bytes` from tile_tot on)
+struct TileCounts { uint32_t *seg_cnt, *tile_tot; size_t zero_bytes; };
 // what the tile-order launch of the forward also does: mark the tiles whose list is long against the frame's total in
 // the launch order (bit 31; render_fwd.hip) and report how many there are and the longest list (GsFwdArgs.frame_stats)
 struct LongLists { int mark; long long* stats; };
 int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
-                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, int debug, hipStream_t s);
+                      uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, bool totals_zeroed, int debug,
+                      hipStream_t s);
 
 // training-step bookkeeping (optim.hip, row N4)
 int launch_densify_stats(int N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
@@ -319,11 +321,10 @@ __device__ __forceinline__ void store_stream(uint4* p, uint4 v) {
     gs_u32x4 x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<gs_u32x4*>(p));
 }
-// mode 0: work = ranges[t].y - ranges[t].x; mode 1: work = keys[4 t .. 4 t + 3] summed; mode 2: work = keys[t] = the
-// tile's pair count, and the tile ranges are written first from (loc, grp): see tile_order_kernel
-int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order,
-                      uint32_t* ranges_out, const uint32_t* loc, const uint32_t* grp, PairCount pc, FillJob fill, LongLists ll,
-                      int debug, hipStream_t s);
+// mode 0: work = ranges[t].y - ranges[t].x; mode 1: work = keys[4 t .. 4 t + 3] summed (mode 2, work = keys[t] = the
+// tile's pair count, runs inside the forward's list-writing launch: binning.hip)
+int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, PairCount pc,
+                      FillJob fill, LongLists ll, int debug, hipStream_t s);
 // per-quadrant compacted lists and their bookkeeping (forward writes, backward reads)
 struct QuadLists {
     uint32_t* qlist;    // [4 D]: quadrant (tile t, q) owns [4 ranges[t].x + q n_t, ... + n_t)

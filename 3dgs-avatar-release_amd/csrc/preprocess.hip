@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int W, int H, float tanfovx, float tanfovy, float focal_x, float focal_y, int gx, int gy, int tile_rect,
     float* __restrict__ rec, float* __restrict__ depths, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals, int32_t* __restrict__ radii,
-    uint32_t* __restrict__ wave_tiles, uint32_t* __restrict__ wave_kmin, uint32_t* __restrict__ wave_kmax, ZeroJob zero) {
-    zero_job(zero);  // the depth sort's digit totals (saves a fill launch)
+    uint32_t* __restrict__ wave_tiles, uint32_t* __restrict__ wave_kmin, uint32_t* __restrict__ wave_kmax, ZeroJob zero,
+    ZeroJob zero2) {
+    zero_job(zero);   // the depth sort's digit totals (saves a fill launch)
+    zero_job(zero2);  // the tile binning's per-tile pair totals (its counting pass adds into them)
     // threads past the end (last workgroup only) redo Gaussian P - 1 and store nothing: every lane of every wave reaches
     // the wave-level sum of tiles touched at the end
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 
 int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* tiles, uint32_t* clamped,
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
-                      uint32_t* wave_kmax, ZeroJob zero, hipStream_t s) {
+                      uint32_t* wave_kmax, ZeroJob zero, ZeroJob zero2, hipStream_t s) {
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
     const float focal_y = a.H / (2.0f * a.tanfovy), focal_x = a.W / (2.0f * a.tanfovx);
     const int blocks = (a.P + 255) / 256;
@@ -169,7 +171,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                        a.scale_modifier, a.rotations, a.opacities, a.shs, a.colors_precomp, a.cov3D_precomp,
                        a.viewmatrix, a.projmatrix, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, focal_x, focal_y, gx, gy,
                        a.tile_rect,
-                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, wave_tiles, wave_kmin, wave_kmax, zero);
+                       rec, depths, tiles, clamped, sort_keys, sort_vals, radii, wave_tiles, wave_kmin, wave_kmax, zero, zero2);
     GS_LAUNCH_CHECK("preprocess", a.debug, s);
     return GS_OK;
 }
