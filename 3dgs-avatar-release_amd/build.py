@@ -68,6 +68,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # code-object extracts that `llvm-objdump --offloading` leaves next to what it inspects do not belong in a directory
+    # that travels to the GPU box with every push
+    for d in (OUT_DIR, OBJ_DIR):
+        for f in os.listdir(d):
+            if ".hipv4-amdgcn" in f or ".host-x86_64" in f:
+                os.remove(os.path.join(d, f))
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

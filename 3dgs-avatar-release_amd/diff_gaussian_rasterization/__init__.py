@@ -181,9 +181,12 @@ _TILE_RECT = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
 
 # GsFwdArgs.long_lists: the machinery for frames of few, long tile lists (a trained avatar: four waves per quadrant in the
 # forward on the tiles whose list is long against the frame's total, backward in chunks) is always used on images of up
-# to 2048 tiles; on larger ones "auto" turns it on when the PREVIOUS frame of the same shape had such tiles (the forward
-# reports them in a pinned word), "1" / "0" force it on / off.  Outputs of the two settings agree to fp32 rounding.
-_LONG_LISTS = os.environ.get("GSPLAT_LONG_LISTS", "auto")
+# to 2048 tiles.  On larger ones it is a setting fixed for the process -- GSPLAT_LONG_LISTS = "0" (default) / "1" -- so that
+# a frame's bits never depend on what was rendered before it (the two settings agree to fp32 rounding, not bit for bit).
+# "auto" is an opt-in: on when the PREVIOUS frame of the same shape had such tiles (the forward reports them in a pinned
+# word that is read without waiting for that frame) -- faster on avatar-shaped frames above 2048 tiles, but the first
+# frame of a shape can then differ from the following ones in the last bits.
+_LONG_LISTS = os.environ.get("GSPLAT_LONG_LISTS", "0")
 _frame_stats = {}  # (device index, W, H) -> pinned int64[2]: [tiles with a long list, longest list] of the last frame
 
 

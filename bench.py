@@ -106,6 +106,11 @@ def parse_args(argv=None):
     ap.add_argument("--train-step", action="store_true",
                     help="also run what follows the backward in the reference's step: densification statistics and the Adam "
                          "update of all parameters (fused N4 ops)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="STRONG scaling: a sequence of this many frames partitioned round-robin over the ranks (rank r "
+                         "renders frames r, r + N, ...: render.py:51-62; BASELINE config 4 is --workload config4 "
+                         "--total-frames 300 --gpus 8); value = total frames / the slowest rank's time.  Default 0: weak "
+                         "scaling, every rank renders --steps frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-upstream-leg", action="store_true", help="skip the second timed leg (tile_rect = 0)")
@@ -188,6 +193,21 @@ def pmc_passes(args, argv):
     return res, "rocprofv3 --pmc child passes of this command (%s), mean per launch" % " | ".join(",".join(c) for c in PMC_PASSES)
 
 
+def frame_plan(rank, world, steps, warmup, total_frames=0):
+    """(frames this rank renders, in order; K = how many of them the timed region covers).  The first 8 + warmup frames are
+    rendered before the timed region (first touches, settle, warm-up), the last K inside it.
+    Weak scaling (total_frames = 0): rank r owns frames r, r + world, ... and times `steps` of them.
+    Strong scaling: the reference's frame loop over a sequence of fixed length (render.py:51-62), partitioned -- rank r
+    times every frame r, r + world, ... below total_frames exactly once (300 frames over 8 ranks: 38 or 37 each)."""
+    from gsplat_mi355.sharding import frames_of_rank
+    if total_frames > 0:
+        own = frames_of_rank(rank, world, total=total_frames)
+        if not own:
+            return [], 0
+        return [own[i % len(own)] for i in range(8 + warmup)] + own, len(own)
+    return frames_of_rank(rank, world, steps + warmup + 8), steps
+
+
 def traffic_bytes(c):
     """HBM-side bytes of one launch from FETCH_SIZE / WRITE_SIZE (rocprofv3 reports KiB): 2 x FETCH_SIZE + WRITE_SIZE.
     On gfx950 FETCH_SIZE counts every read request of the L2 -- a 128-byte line -- as 64 bytes
@@ -259,11 +279,24 @@ def main(argv=None):
         cloud = broadcast_cloud(cloud, N, deg, dev, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
+    state_sums = None
+    if world > 1:
+        # evidence that every rank renders the SAME Gaussian state: a checksum of the packed buffer's bit patterns per rank
+        cs = cloud.pack().view(torch.int32).to(torch.int64).sum().reshape(1)
+        if rehearsal:
+            cs = cs.cpu()
+        got = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(got, cs)
+        state_sums = [int(g.item()) for g in got]
     for f in GaussianCloud.FIELDS:
         getattr(cloud, f).requires_grad_(do_bwd)
 
-    K, Wm = args.steps, args.warmup
-    frames = frames_of_rank(rank, world, K + Wm + 8)
+    Wm = args.warmup
+    strong = args.total_frames > 0
+    frames, K = frame_plan(rank, world, args.steps, Wm, args.total_frames)
+    if K == 0:
+        print("bench.py: --total-frames %d leaves rank %d of %d without a frame" % (args.total_frames, rank, world), file=sys.stderr)
+        sys.exit(2)
     cams = [orbit_camera(f, W, H, device=dev) for f in frames]
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     bg = torch.zeros(3, device=dev)
@@ -327,8 +360,9 @@ def main(argv=None):
         return
 
     groups = {"preprocess": ["preprocess"],
-              "binning": ["pair_scan", "depth_sort", "rank_list", "tile_count", "seg_prefix", "ranges_order", "tile_write"],
-              "render_fwd": ["render_fwd"], "render_bwd": ["render_bwd"], "gaussian_bwd": ["gaussian_bwd"]}
+              "binning": ["pair_scan", "depth_sort", "rank_list", "tile_count", "ranges_order", "tile_write"],
+              "render_fwd": ["render_fwd", "recolor", "second_ones"], "render_bwd": ["render_bwd"],
+              "gaussian_bwd": ["gaussian_bwd"]}
     kernel_stages = ["preprocess", "render_fwd", "render_bwd", "gaussian_bwd"]
 
     def run_leg(tile_rect):
@@ -407,6 +441,20 @@ def main(argv=None):
         gc.enable()
         dom = _lib.profile_collect().get(dominant, (0.0, 0))
         _lib.profile_enable(False)
+        # Per-stage times, taken NOW: right behind the timed loop, on the same settled clocks and over the same frames, one
+        # stage per pass (two HIP events per call -- bracketing every stage at once adds ~2-4 us of event handling per
+        # stage to the frame).  Taken before the settle steps, as until round 2, they read ~15 % high and added up to more
+        # than ms_per_step.
+        post = {}
+        for name in sorted(stage_ms):
+            _lib.profile_enable(True, stage=name)
+            for i in range(8):
+                step(8 + Wm + (i % max(K, 1)))
+            got = _lib.profile_collect().get(name)
+            if got and got[1]:
+                post[name] = got[0] / 8.0  # ms per frame (a stage may run more than once per frame)
+        _lib.profile_enable(False)
+        stage_ms = post or stage_ms
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -416,15 +464,28 @@ def main(argv=None):
         dom_ms = dom[0] / max(dom[1], 1)
         achieved = sb[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_bytes = sum(sb.values()) if do_bwd else sb["preprocess"] + sb["binning"] + sb["render_fwd"]
+        total_frames = args.total_frames if strong else world * K
+        per_rank = total_frames / world  # frames per rank (strong scaling: the average; the slowest rank sets `elapsed`)
+        ms_step = elapsed / per_rank * 1e3
+        grouped = {g: sum(stage_ms.get(st, 0.0) for st in ss) for g, ss in groups.items()}
+        in_groups = {st for ss in groups.values() for st in ss}
+        for st, v in stage_ms.items():  # stages outside the five SURVEY 8(d) groups: losses, the backward's tile order + mark fill
+            if st not in in_groups:
+                grouped[st] = v
+        # what the step spends outside the library's stages: torch glue launches (autograd's ones-fill, grad * g, the
+        # zero leaf), gaps between kernels, host pacing -- so that the entries add up to ms_per_step
+        grouped["outside_stages"] = max(ms_step - sum(grouped.values()), 0.0) if world == 1 else 0.0
+        stage_frac = {g: round(sb[g] / (grouped[g] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for g in sb if grouped.get(g, 0.0) > 0}
         return {
-            "fps": world * K / elapsed, "ms_per_step": elapsed / K * 1e3, "elapsed": elapsed, "D": D, "visible": vis,
+            "fps": total_frames / elapsed, "ms_per_step": ms_step, "elapsed": elapsed, "D": D, "visible": vis, "K": K,
+            "stages_frac": stage_frac,
             "mean_contrib": mean_contrib, "quad_hits": quad_hits, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
-            "stages_ms": {g: round(sum(stage_ms.get(s, 0.0) for s in ss), 4) for g, ss in groups.items()},
+            "stages_ms": {g: round(v, 4) for g, v in grouped.items()},
         }
 
     default_rect = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
@@ -468,6 +529,10 @@ def main(argv=None):
                 rec["insts_per_launch"] = insts
                 rec["issue_slot_util"] = round(insts * 2.0 / (SIMDS * CLOCK_HZ * ms * 1e-3), 4)
             valu[stage] = rec
+        if dominant in valu and "issue_slot_util" in valu[dominant]:
+            # the ceiling that actually binds the dominant kernel, next to the HBM one the contract asks for
+            roof["binding"] = {"ceiling": "VALU issue slots (one wave64 instruction per SIMD-32 every 2 cycles)",
+                               "frac": valu[dominant]["issue_slot_util"], "kernel": dominant}
         roof["valu"] = {"peak_tflops": VALU_PEAK_TFLOPS, "simds": SIMDS, "clock_hz": CLOCK_HZ,
                         "note": "secondary ceiling (SURVEY.md 8d): the render kernels are VALU-issue bound, not HBM bound; "
                                 "issue_slot_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
@@ -477,8 +542,9 @@ def main(argv=None):
         out = {
             "metric": "render fps (fwd+bwd) @200k Gaussians 1024x1024 SH3" if args.workload == "config3"
             else "render fps (%s) @%s" % ("fwd+bwd" if do_bwd else "fwd", args.workload),
-            "value": round(main_leg["fps"], 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(main_leg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(main_leg["fps"], 2), "unit": "frames/s", "n_gpus": world,
+            "steps": (args.total_frames + world - 1) // world if strong else K, "warmup": Wm,
+            "ms_per_step": round(main_leg["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
@@ -488,12 +554,16 @@ def main(argv=None):
                 ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
                 "tile_rect": default_rect, "gaussians": N, "visible": main_leg["visible"], "width": W, "height": H,
                 "sh_degree": deg, "num_rendered": main_leg["D"], "mean_n_contrib": round(main_leg["mean_contrib"], 2),
-                "frames_per_rank": K, "ranks": world,
+                "frames_per_rank": ([args.total_frames // world, (args.total_frames + world - 1) // world] if strong else K),
+                "total_frames": args.total_frames if strong else world * K, "ranks": world,
                 "backend": "none" if world == 1 else ("gloo (REHEARSAL: all ranks on one GPU)" if rehearsal else "nccl (RCCL)"),
                 "parallelism": "frames sharded x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
-                "broadcast_s": round(t_bcast, 6)},
+                "broadcast_s": round(t_bcast, 6), "state_checksums": state_sums},
             "roofline": roof,
+            # per frame, measured right behind the timed loop, one stage per pass; the entries add up to ms_per_step
+            # (`outside_stages` = torch glue launches, gaps, host pacing); stages_frac = algorithmic bytes / time / 8 TB/s
             "stages_ms": main_leg["stages_ms"],
+            "stages_frac": main_leg["stages_frac"],
             "stages_detail_ms": {k: round(v, 4) for k, v in sorted(main_leg["stage_ms"].items())},
         }
         if up_leg is not None:
@@ -501,7 +571,7 @@ def main(argv=None):
             out["upstream_rect"] = {"tile_rect": 0, "value": round(up_leg["fps"], 2), "unit": "frames/s",
                                     "ms_per_step": round(up_leg["ms_per_step"], 4), "num_rendered": up_leg["D"],
                                     "mean_n_contrib": round(up_leg["mean_contrib"], 2), "roofline": up_leg["roofline"],
-                                    "stages_ms": up_leg["stages_ms"]}
+                                    "stages_ms": up_leg["stages_ms"], "stages_frac": up_leg["stages_frac"]}
         if per_kernel:
             out["pmc_per_kernel"] = per_kernel
         if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,8 @@ from ctypes import POINTER, c_double, c_float, c_int, c_int64, c_uint8, c_uint32
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libgs_oracle.so")
+# GS_ORACLE_SO: another build of the same source (the sanitizer build of `make SAN=1`: tests/test_oracle_sanitized.py)
+_SO = os.environ.get("GS_ORACLE_SO") or os.path.join(_HERE, "_build", "libgs_oracle.so")
 
 
 class OrArgs(ctypes.Structure):

@@ -89,3 +89,41 @@ def test_gpus_flag_starts_the_ranks_itself_and_refuses_a_mismatch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "4"])
     assert e.value.code == 2
+
+
+def test_total_frames_is_config_4_as_stated_300_frames_partitioned_over_the_ranks(monkeypatch):
+    """BASELINE config 4: a 300-frame sequence sharded over 8 GPUs (render.py:51-62 is the loop being partitioned).
+    `--total-frames 300`: rank r times frames r, r + 8, ... exactly once (38 or 37 frames: the tail SURVEY.md 8(e) names),
+    every frame of the sequence is timed by exactly one rank, and the flag reaches the ranks bench.py starts itself."""
+    import subprocess
+
+    import bench
+    import pytest
+    timed = []
+    for r in range(8):
+        frames, K = bench.frame_plan(r, 8, steps=100, warmup=5, total_frames=300)
+        assert K == (38 if r < 4 else 37) and len(frames) == 8 + 5 + K
+        assert frames[-K:] == list(range(r, 300, 8))
+        assert set(frames[:13]) <= set(frames[-K:])  # the untimed frames are this rank's own, re-used
+        timed += frames[-K:]
+    assert sorted(timed) == list(range(300))
+    # weak scaling (the default): every rank times --steps frames of its own
+    frames, K = bench.frame_plan(3, 8, steps=20, warmup=5)
+    assert K == 20 and frames == [3 + 8 * i for i in range(33)]
+    assert bench.frame_plan(5, 8, steps=20, warmup=5, total_frames=4) == ([], 0)  # more ranks than frames: refused in main()
+    a = bench.parse_args(["--gpus", "8", "--workload", "config4", "--total-frames", "300"])
+    assert a.total_frames == 300 and a.workload == "config4"
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"] = cmd
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "8", "--workload", "config4", "--total-frames", "300"])
+    assert seen["cmd"][-6:] == ["--gpus", "8", "--workload", "config4", "--total-frames", "300"]

@@ -379,9 +379,10 @@ def test_long_lists_on_a_small_image_backward_in_chunks(oracle, with_opacity):
 
 def test_long_lists_on_a_large_image_follow_the_previous_frames_statistics(oracle, monkeypatch):
     """Above 2048 tiles the few-long-lists machinery (four-wave forward, backward in chunks) is the caller's choice
-    (GsFwdArgs.long_lists): the wrapper takes it from the statistics the forward of the PREVIOUS frame of the same shape
-    left in a pinned word.  A trained-avatar shaped frame on 800 x 800 (2500 tiles): the first frame runs without it and
-    reports its long lists, the second runs with it; both match the oracle, and each other to fp32 rounding."""
+    (GsFwdArgs.long_lists).  With the OPT-IN GSPLAT_LONG_LISTS=auto the wrapper takes it from the statistics the forward
+    of the PREVIOUS frame of the same shape left in a pinned word.  A trained-avatar shaped frame on 800 x 800 (2500
+    tiles): the first frame runs without it and reports its long lists, the second runs with it; both match the oracle,
+    and each other to fp32 rounding.  (The default is a fixed setting: test_large_images_do_not_depend_on_call_history.)"""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device("cuda:0")
@@ -424,6 +425,53 @@ def test_long_lists_on_a_large_image_follow_the_previous_frames_statistics(oracl
     monkeypatch.setattr(dgr, "_LONG_LISTS", "0")
     m2, c = frame()
     assert m2 == 0 and all(np.array_equal(a[k], c[k]) for k in a)  # forced off: the first frame's bits again
+
+
+@pytest.mark.parametrize("pin", ["default", "0", "1"])
+def test_large_images_do_not_depend_on_call_history(pin, monkeypatch):
+    """Above 2048 tiles GsFwdArgs.long_lists is a setting fixed for the process (GSPLAT_LONG_LISTS = 0 by default, or 1),
+    never a function of earlier frames: the same scene rendered from a cold wrapper state (no statistics word, no pair
+    count estimate, nothing on offer), rendered again, and rendered again after an unrelated frame of the same shape has
+    been through the wrapper, gives the same bits every time -- image, radii and every gradient -- under either setting."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    n, W, H = 60000, 800, 800  # 2500 tiles; a trained-avatar shaped frame: its long lists would flip "auto" after a frame
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=6, layout="body")
+    other, _ = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=7)
+    bg = (0.3, 0.2, 0.1)
+    if pin != "default":
+        monkeypatch.setattr(dgr, "_LONG_LISTS", pin)
+    assert dgr._LONG_LISTS == ("0" if pin == "default" else pin)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def cold():
+        dgr._frame_stats.clear()
+        dgr._last_count.clear()
+        dgr.release_shared_geometry()
+
+    def frame(c):
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(c, cam, "sh", "scale_rot", dev).items()}
+        means3D = c.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = c.opacity.to(dev).requires_grad_(True)
+        color, radii = GaussianRasterizer(_settings(cam, c, bg, dev))(means3D=means3D, means2D=means2D, opacities=opac, **kw)
+        mode = color.grad_fn.long_lists
+        (color * gimg).sum().backward()
+        out = [color.detach(), radii, means3D.grad, means2D.grad, opac.grad] + [v.grad for v in kw.values()]
+        return mode, out
+
+    cold()
+    m0, a = frame(cloud)
+    m1, b = frame(cloud)
+    frame(other)
+    m2, c = frame(cloud)
+    cold()
+    m3, d = frame(cloud)
+    want = 1 if pin == "1" else 0
+    assert (m0, m1, m2, m3) == (want,) * 4
+    for x, y, z, w in zip(a, b, c, d):
+        assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, w)
 
 
 @pytest.mark.parametrize("W,H", [(1500, 90), (90, 1500), (1100, 1090), (2070, 40)])
@@ -599,7 +647,7 @@ def _sorted_list_properties(st):
 
 
 def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_pairs=0, extra_properties=False,
-                    layout="box"):
+                    layout="box", sh_degree=3):
     """One BASELINE configuration at FULL size through the HIP path against the oracle in the same binning mode:
     integers (radii, tiles_touched, num_rendered, the sorted (tile, depth) list, the tile ranges) bit-exact; image,
     final_T and all six gradient tensors inside the float bar with bounded outliers; errors recorded in the parity
@@ -608,8 +656,8 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
     from gsplat_mi355 import debug
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda:0")
-    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=3, seed=0, frame=frame, heavy_tail=heavy_tail, layout=layout,
-                                          dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=sh_degree, seed=0, frame=frame, heavy_tail=heavy_tail,
+                                          layout=layout, dist2_fn=lambda p: distCUDA2(p.to(dev)).cpu())
     bg = (0.0, 0.0, 0.0)
     sc = helpers.oracle_scene(cloud, cam, bg=bg, tile_rect=tile_rect)
     fw = oracle.forward(sc)
@@ -668,6 +716,13 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
         both, second = grads(g1 + g2), grads(g2)
         for k in got:
             _bulk_close(both[k], got[k] + second[k], tol=2e-5, frac=2e-4, name="linearity " + k)
+
+
+def test_full_size_config1_shape_10k_256_sh0_on_the_hip_path(oracle, tile_rect):
+    """BASELINE config 1 (dummy_dataset: 10k random Gaussians, 256 x 256, SH degree 0) is by definition the no-GPU
+    plumbing configuration and runs on the CPU oracle (tests/test_oracle.py); this is the same shape through the HIP
+    path, forward + backward against the oracle in both binning modes, so that no BASELINE shape is left unexercised."""
+    _full_size_case(oracle, "config1 10k/256x256 SH0", 10000, 256, 256, 0.0, tile_rect, min_pairs=10000, sh_degree=0)
 
 
 def test_full_size_config3_200k_1024_forward_backward(oracle, tile_rect):
@@ -783,7 +838,7 @@ def _two_call_step(oracle, monkeypatch, scene, bg, mode, use):
     import diff_gaussian_rasterization as dgr
     from gsplat_mi355 import _lib
     from gsplat_mi355.render import Pipe, render
-    assert dgr._SHARE and dgr._FUSE_SECOND and dgr._SPECULATE and dgr._LONG_LISTS == "auto"  # the defaults are under test
+    assert dgr._SHARE and dgr._FUSE_SECOND and dgr._SPECULATE and dgr._LONG_LISTS == "0"  # the defaults are under test
     dev = torch.device("cuda:0")
     n, W, H, layout = _TWO_CALL_SCENES[scene]
     cloud, cam, sc, fw, sc1, fw1 = _two_call_reference(oracle, scene, bg)
@@ -1026,18 +1081,34 @@ def test_shared_geometry_second_render_is_bitwise_identical(oracle, fused_backwa
         # opacity render = 1 - T for a black background (gaussian_renderer/__init__.py:131-142)
         sc1 = helpers.oracle_scene(cloud, cam, color_mode="precomp", colors=torch.ones(n, 3), cov_mode="cov")
         _bulk_close(shared[1].cpu().numpy(), oracle.forward(sc1)["color"], name="opacity pass")
-        # an in-place update of the positions must not be served from the cache
+        # An in-place update of the positions between two calls must not be served from the first call's geometry -- under
+        # GRAD mode, where sharing is live (under no_grad nothing is ever offered): the offer is keyed by the tensors'
+        # autograd version counters.  `alias` is a detached view of the same storage: writing through it bumps the
+        # counter the leaf shares with it.
         dgr._SHARE = True
         dgr.release_shared_geometry()
-        xyz = cloud.xyz.to(dev)
+        xyz = cloud.xyz.to(dev).requires_grad_(True)
+        m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
         op, cov = cloud.opacity.to(dev), helpers.covariance6_cpu(cloud).to(dev)
         ones = torch.ones(n, 3, device=dev)
         rast = GaussianRasterizer(settings)
-        with torch.no_grad():
-            a1, _ = rast(means3D=xyz, means2D=xyz, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
-            xyz.add_(0.05)
-            a2, _ = rast(means3D=xyz, means2D=xyz, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
-        assert not torch.equal(a1, a2)
+        h0 = dgr._geom_cache.hits
+        a1, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        alias = xyz.detach()
+        alias.add_(0.05)
+        assert alias.data_ptr() == xyz.data_ptr()
+        a2, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        assert dgr._geom_cache.hits == h0 and not torch.equal(a1, a2)  # a miss: rendered in full from the new positions
+        a3, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        assert dgr._geom_cache.hits == h0 + 1  # (nothing changed since a2: served from its geometry)
+        # `.data` writes are invisible to the version counter -- to the cache as to autograd's own saved-tensor checks:
+        # unsupported between two calls without a backward in between; release_shared_geometry() is the way out.
+        dgr.release_shared_geometry()
+        b1, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        xyz.data.add_(0.05)
+        dgr.release_shared_geometry()
+        b2, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=ones, cov3D_precomp=cov)
+        assert dgr._geom_cache.hits == h0 + 1 and not torch.equal(b1, b2)
     finally:
         dgr._SHARE = True
         dgr.release_shared_geometry()
