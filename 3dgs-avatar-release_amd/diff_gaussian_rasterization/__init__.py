@@ -332,7 +332,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = torch.cuda.current_stream(dev)
             sptr = ctypes.c_void_p(stream.cuda_stream)
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
-            share = _SHARE and any(ctx.needs_input_grad)  # (true only under grad mode)
+            # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
+            # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
+            share = _SHARE and torch.is_grad_enabled() and any(ctx.needs_input_grad)
             gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream.cuda_stream)
                     if share else None)
             hit = _geom_cache.take(dev, gkey) if share else None
