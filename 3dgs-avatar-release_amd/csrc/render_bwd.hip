@@ -84,16 +84,50 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
         : "scc");
 }
 
-// the nine per-entry values the inner loop reads (+ the entry's colour in a second image of the same geometry)
-template <bool SECOND>
-struct EntryT {
-    float x, y, A2, B2, C2, o, r, g, b;
+// The per-entry values the inner loop reads, as the three 16-byte quads they are staged with in LDS:
+// q0 = (x, y, A2, B2), q1 = (C2, opacity, r, g), q2 = (b, and the entry's colour in a second image of the same geometry)
+typedef float bwd_f4 __attribute__((ext_vector_type(4)));
+struct EntryQ {
+    bwd_f4 q0, q1, q2;
 };
-template <>
-struct EntryT<true> {
-    float x, y, A2, B2, C2, o, r, g, b, r2, g2, b2;
-};
+#define ENT_SLOTS 2  // chunks of 16 staged entries in LDS: the one the lanes are switching to, the one after it
 
+// Entry switch.  Position t of every ring takes its entry of the round's chunk at step t -- one lane per ring and step.
+// Moving nine values under a one-lane exec mask costs nine VALU issue slots per step (an instruction costs the same with 1
+// or 64 lanes on): here the LDS unit does it instead.  The lanes of `m1 & ~m0` (those that switch at the NEXT step) read
+// their new entry from its staged copy straight into the working registers; no other lane is written.  Issue and wait
+// sit in one block: between two blocks the compiler would be free to copy registers whose load is still in flight.
+template <bool SECOND>
+__device__ __forceinline__ void switch_entry(EntryQ& e, uint32_t lds_addr, unsigned long long m0, unsigned long long m1) {
+    unsigned long long save;
+    if constexpr (SECOND) {
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m0]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b128 %[q2], %[a] offset:32\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [q0] "+v"(e.q0), [q1] "+v"(e.q1), [q2] "+v"(e.q2), [sv] "=&s"(save)
+            : [a] "v"(lds_addr), [m0] "s"(m0), [m1] "s"(m1)
+            : "memory", "scc");
+    } else {
+        float b = e.q2.x;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m0]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b32 %[b], %[a] offset:32\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [q0] "+v"(e.q0), [q1] "+v"(e.q1), [b] "+v"(b), [sv] "=&s"(save)
+            : [a] "v"(lds_addr), [m0] "s"(m0), [m1] "s"(m1)
+            : "memory", "scc");
+        e.q2.x = b;
+    }
+}
 
 // OPA: the image has a fourth channel whose "colour" is 1 for every Gaussian -- the opacity render the reference
 // obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
@@ -116,13 +150,14 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
                                                         const uint32_t* __restrict__ ck_start, const int chunks,
                                                         const int blocks_per_chunk, const SecondImage second) {
     constexpr bool OPA = MODE == 1, SECOND = MODE == 2;
-    typedef EntryT<SECOND> Entry;
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
     // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
     __shared__ float pix[OPA ? 7 : (SECOND ? 9 : 6)][4 * RING_STRIDE];  // (+ the opacity channel's gradient / the second image's)
+    // the converted entries of a chunk, staged by ring 0 at a round start for the switch reads of the NEXT round
+    __shared__ bwd_f4 ent[ENT_SLOTS][RING][3];
     int slot, q;
     // chunk-major: all first chunks, heaviest tiles first, then all second chunks, ... (chunks = 1: one wave per quadrant)
     const int chunk = chunks > 1 ? (int)blockIdx.x / blocks_per_chunk : 0;
@@ -196,18 +231,20 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         gtot0 = c0.w;
     }
 
-    // record (p0,p1,p2) -> the loop's entry form + the gradient row of (pair, quadrant)
-    auto convert = [&](const float4 p0, const float4 p1, const float4 p2, Entry& e, uint32_t& row) {
-        e.x = p0.x; e.y = p0.y;
-        e.A2 = (-0.5f * LOG2E_F) * p0.z;
-        e.B2 = -LOG2E_F * p0.w;
-        e.C2 = (-0.5f * LOG2E_F) * p1.x;
-        e.o = p1.y; e.r = p1.z; e.g = p1.w; e.b = p2.x;
+    // record (p0,p1,p2) -> the loop's entry form, staged in LDS slot `chunk & 1` by ring 0 (the four rings hold the same
+    // entries), + the gradient row of (pair, quadrant)
+    float3 q2 = make_float3(0.f, 0.f, 0.f);  // (SECOND) the gathered entry's colour in the second image
+    auto stage = [&](const float4 p0, const float4 p1, const float4 p2, const int chunk, uint32_t& row) {
         const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
         const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu, h = rsz >> 16;
         row = gradient_row(off, w, h, ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx), (uint32_t)q);
+        if (ring == 0) {
+            bwd_f4* e = ent[chunk & (ENT_SLOTS - 1)][j];
+            e[0] = bwd_f4{p0.x, p0.y, (-0.5f * LOG2E_F) * p0.z, -LOG2E_F * p0.w};
+            e[1] = bwd_f4{(-0.5f * LOG2E_F) * p1.x, p1.y, p1.z, p1.w};
+            e[2] = bwd_f4{p2.x, q2.x, q2.y, q2.z};
+        }
     };
-    float3 q2 = make_float3(0.f, 0.f, 0.f);  // (SECOND) the gathered entry's colour in the second image
     auto gather = [&](int k, float4& p0, float4& p1, float4& p2) {
         if (k < m) {
             const uint32_t id = qlist[qbase + k];
@@ -217,18 +254,17 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             if (SECOND) q2 = make_float3(second.colors[(size_t)id * 3], second.colors[(size_t)id * 3 + 1], second.colors[(size_t)id * 3 + 2]);
         }
     };
-    auto convert2 = [&](Entry& e) {  // (after convert, before the next gather)
-        if constexpr (SECOND) { e.r2 = q2.x; e.g2 = q2.y; e.b2 = q2.z; }
-    };
 
     float4 p0 = zero4, p1 = zero4, p2 = zero4;
-    Entry cur = {}, nxt = {};
-    uint32_t nxt_row = 0;  // gradient row of the entry in `nxt`
+    EntryQ cur;  // the entry this lane works on (none yet: alpha = 0)
+    cur.q0 = cur.q1 = cur.q2 = bwd_f4{0.f, 0.f, 0.f, 0.f};
+    uint32_t row_staged = 0;  // gradient row of this lane's entry in the chunk staged last
     gather(j, p0, p1, p2);              // (the four rings hold the same entries)
-    convert(p0, p1, p2, nxt, nxt_row);  // chunk 0, taken by position t of every ring at step t
-    convert2(nxt);
+    stage(p0, p1, p2, 0, row_staged);   // chunk 0, taken by position t of every ring at step t
     gather(RING + j, p0, p1, p2);       // chunk 1 in flight during round 0
     __syncthreads();
+    // LDS address of this lane's entry in the two slots
+    const uint32_t ent_addr0 = (uint32_t)(uintptr_t)&ent[0][j][0], ent_addr1 = (uint32_t)(uintptr_t)&ent[1][j][0];
 
     // Two accumulator sets, named by the PARITY of the chunk they belong to: during round R the lanes
     // that have already taken their entry of chunk R (lane <= t) add into set R & 1, the others still
@@ -274,27 +310,26 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         }
     };
     auto run_round = [&](const int s0, float (&X)[9], uint32_t& rowX, float (&Y)[9]) {
-        if (s0 > 0) {
-            // round start: every lane took its entry of the previous chunk out of `nxt` during the
-            // previous round.  X holds the finished sums of the chunk before that one: store them.  The
-            // chunk that was in flight -> `nxt`; the chunk after it -> in flight.
-            if (s0 >= 2 * RING) {
-                fold_rings(X);
-                if (ring == 0) write_row(rowX, X);
-            }
-            convert(p0, p1, p2, nxt, nxt_row);
-            convert2(nxt);
-            gather(s0 + RING + j, p0, p1, p2);
-            pidx -= (uint32_t)RING;
+        // Round start (round R = s0 / 16).  X holds the finished sums of chunk R - 2: store them.  The lanes switch to
+        // chunk R during this round (staged one round ago): its row is the one noted then.  The chunk that was in flight
+        // (R + 1) is converted and staged for the next round; the chunk after it goes in flight.
+        if (s0 >= 2 * RING) {
+            fold_rings(X);
+            if (ring == 0) write_row(rowX, X);
         }
-        rowX = nxt_row;
+        rowX = row_staged;
+        const uint32_t ea = (s0 & RING) ? ent_addr1 : ent_addr0;  // this round's chunk: slot R & 1
+        // position 0 of every ring takes its entry now (the other positions at the end of the step before theirs)
+        switch_entry<SECOND>(cur, ea, 0ull, 0x0001000100010001ull);
+        stage(p0, p1, p2, s0 / RING + 1, row_staged);  // (behind the read above: slot (R + 1) & 1 held chunk R - 1)
+        gather(s0 + 2 * RING + j, p0, p1, p2);
+        if (s0 > 0) pidx -= (uint32_t)RING;
 #pragma unroll
         for (int c9 = 0; c9 < 9; c9++) X[c9] = 0.f;
         const int tend = min(RING, total - s0);
         unsigned long long mx = 0x0001000100010001ull;  // ring positions <= t, kept up to date step by step
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
-            if (j == t) cur = nxt;  // position t of every ring takes its entry of the new chunk
             const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[3], pyf = pc[4];
             const uint32_t lim = __float_as_uint(pc[5]);
@@ -304,11 +339,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             pidx += 1u;
 #pragma unroll
             for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
-            const float dx = cur.x - pxf, dy = cur.y - pyf;
+            const float dx = cur.q0.x - pxf, dy = cur.q0.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
-            const float power2 = __builtin_fmaf(cur.A2 * dx, dx, __builtin_fmaf(cur.B2, dx, cur.C2 * dy) * dy);
+            const float power2 = __builtin_fmaf(cur.q0.z * dx, dx, __builtin_fmaf(cur.q0.w, dx, cur.q1.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
-            const float al = fminf(0.99f, cur.o * G);
+            const float al = fminf(0.99f, cur.q1.y * G);
             // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
             // power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that has no
             // entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's
@@ -319,9 +354,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             const float alpha = valid ? a2 : 0.f;
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
-            float cg = cur.r * g.x + cur.g * g.y + cur.b * g.z;
+            float cg = cur.q1.z * g.x + cur.q1.w * g.y + cur.q2.x * g.z;
             if constexpr (OPA) cg += g4;
-            if constexpr (SECOND) cg += cur.r2 * h0 + cur.g2 * h1 + cur.b2 * h2;
+            if constexpr (SECOND) cg += cur.q2.y * h0 + cur.q2.z * h1 + cur.q2.w * h2;
             Rem = __builtin_fmaf(-cg, wgt, Rem);
             const float one_m = 1.f - alpha;
             const float dL_dalpha = T * cg - Rem * __builtin_amdgcn_rcpf(one_m);
@@ -332,7 +367,10 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             //        6..8: w g_c = dL/dcolor     (t = Gd)
             // X += ... on the lanes <= t (they have taken their entry of this round's chunk), Y += ... on the others
             split_accumulate(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
-            mx = (mx << 1) | 0x0001000100010001ull;
+            // the positions that take their entry at the next step read it now (none after the round's last step)
+            const unsigned long long mx1 = (mx << 1) | 0x0001000100010001ull;
+            switch_entry<SECOND>(cur, ea, mx, mx1);
+            mx = mx1;
             // the pixel moves on to the next entry = the next lane
             T = ring_ror1(T);
             Rem = ring_ror1(Rem);

@@ -250,6 +250,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     if (_FUSE_SECOND and _SHARE and not with_opacity and torch.is_grad_enabled() and colors_precomp is not None
             and colors_precomp.numel() and not colors_precomp.requires_grad and (sh is None or sh.numel() == 0)):
         dep = _second_render_dependency(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+    _tls.grad_mode = torch.is_grad_enabled()  # (inside Function.forward grad mode is always off)
     color, radii, opacity = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                                        cov3Ds_precomp, raster_settings, bool(with_opacity), dep)
     return (color, radii, opacity) if with_opacity else (color, radii)
@@ -334,7 +335,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
             # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
-            share = _SHARE and torch.is_grad_enabled() and any(ctx.needs_input_grad)
+            share = _SHARE and getattr(_tls, "grad_mode", True) and any(ctx.needs_input_grad)
             gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream.cuda_stream)
                     if share else None)
             hit = _geom_cache.take(dev, gkey) if share else None
