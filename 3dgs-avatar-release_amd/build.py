@@ -68,6 +68,11 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # render_bwd.hip issues LDS reads in one inline-asm block and waits for them in the next: verify in the generated
+    # code that nothing in between touches the registers they land in (tools/check_inflight.py)
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import check_inflight
+    check_inflight.check(os.path.join(OBJ_DIR, "render_bwd.o"))
     # code-object extracts that `llvm-objdump --offloading` leaves next to what it inspects do not belong in a directory
     # that travels to the GPU box with every push
     for d in (OUT_DIR, OBJ_DIR):

@@ -48,12 +48,26 @@ __device__ __forceinline__ float ring_ror1(float v) {
 // y[0..8] += the same on all other lanes: the nine instructions issued twice under complementary exec
 // masks.  (Written as if / else the compiler either flattens the two blocks into three selects per sum
 // or indexes the sets through scratch memory.)  The caller runs with all 64 lanes on.
+//
+// ENTRY SWITCH, riding in the same two blocks.  Position t of every ring takes its entry of the round's chunk at step t --
+// one lane per ring and step.  Moving nine values under a one-lane exec mask costs nine VALU issue slots per step (an
+// instruction costs the same with 1 or 64 lanes on): here the LDS unit does it instead.  The lanes of `m1 & ~mask` (those
+// that switch at the NEXT step; the accumulation is the last thing of a step that reads the entry... and it does not)
+// read their new entry from its staged copy straight into the working registers (q0, q1, q2): no other lane is written.
+// The reads are issued in front of the first nine instructions and waited for behind the second nine.
+typedef float bwd_f4 __attribute__((ext_vector_type(4)));
+template <bool SECOND>
 __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], unsigned long long mask, float Gd, float dx,
                                                  float dy, float tdx, float tdy, float wgt, float gx, float gy,
-                                                 float gz) {
+                                                 float gz, unsigned long long m1, uint32_t lds_addr, bwd_f4& q0, bwd_f4& q1,
+                                                 bwd_f4& q2) {
     unsigned long long save;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
+        "s_andn2_b64 exec, %[m1], %[m]\n\t"
+        "ds_read_b128 %[q0], %[a]\n\t"
+        "ds_read_b128 %[q1], %[a] offset:16\n\t"
+        "ds_read_b128 %[q2], %[a] offset:32\n\t"
         "s_mov_b64 exec, %[m]\n\t"
         "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"
         "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"
@@ -64,6 +78,16 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
         "v_fmac_f32 %[x6], %[w], %[gx]\n\t"
         "v_fmac_f32 %[x7], %[w], %[gy]\n\t"
         "v_fmac_f32 %[x8], %[w], %[gz]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
+          [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [sv] "=&s"(save)
+        : [m] "s"(mask), [m1] "s"(m1), [a] "v"(lds_addr), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx),
+          [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
+        : "memory", "scc");
+    // (nothing may touch q0 / q1 / q2 between the two blocks: their loads are in flight.  The blocks are adjacent
+    // statements; the second one names the registers as in / out operands, so it cannot be moved in front of a use.)
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
         "s_andn2_b64 exec, %[sv], %[m]\n\t"
         "v_fmac_f32 %[y0], %[Gd], %[dx]\n\t"
         "v_fmac_f32 %[y1], %[Gd], %[dy]\n\t"
@@ -74,19 +98,17 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
         "v_fmac_f32 %[y6], %[w], %[gx]\n\t"
         "v_fmac_f32 %[y7], %[w], %[gy]\n\t"
         "v_fmac_f32 %[y8], %[w], %[gz]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
-          [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]),
-          [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]), [y7] "+v"(y[7]), [y8] "+v"(y[8]),
-          [sv] "=&s"(save)
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]),
+          [y6] "+v"(y[6]), [y7] "+v"(y[7]), [y8] "+v"(y[8]), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [sv] "=&s"(save)
         : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt),
           [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
-        : "scc");
+        : "memory", "scc");
 }
 
 // The per-entry values the inner loop reads, as the three 16-byte quads they are staged with in LDS:
 // q0 = (x, y, A2, B2), q1 = (C2, opacity, r, g), q2 = (b, and the entry's colour in a second image of the same geometry)
-typedef float bwd_f4 __attribute__((ext_vector_type(4)));
 struct EntryQ {
     bwd_f4 q0, q1, q2;
 };
@@ -366,10 +388,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             // sums:  0: t dx   1: t dy   2: t dx^2   3: t dx dy   4: t dy^2   5: G dL/dalpha = dL/dopacity
             //        6..8: w g_c = dL/dcolor     (t = Gd)
             // X += ... on the lanes <= t (they have taken their entry of this round's chunk), Y += ... on the others
-            split_accumulate(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z);
-            // the positions that take their entry at the next step read it now (none after the round's last step)
+            // ... and the positions that take their entry at the next step read it meanwhile (none after the round's last step)
             const unsigned long long mx1 = (mx << 1) | 0x0001000100010001ull;
-            switch_entry<SECOND>(cur, ea, mx, mx1);
+            split_accumulate<SECOND>(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z, mx1, ea, cur.q0, cur.q1, cur.q2);
             mx = mx1;
             // the pixel moves on to the next entry = the next lane
             T = ring_ror1(T);
