@@ -50,6 +50,19 @@ class RenderPackage(object):
             raise AttributeError(item)
 
 
+_zeros = {}  # (device, shape, dtype) -> an all-zero tensor, never written
+
+
+def _zero_leaf(like):
+    key = (like.device, tuple(like.shape), like.dtype)
+    z = _zeros.get(key)
+    if z is None:
+        if len(_zeros) > 64:
+            _zeros.clear()
+        z = _zeros[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return z.detach().requires_grad_(True)
+
+
 def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, return_opacity=False):
     """data: camera (FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
     camera_center); pc: tensors named as GaussianModel's getters (xyz, opacity, scales, rotations, shs).
@@ -59,7 +72,9 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
     # gaussian_renderer/__init__.py:76-80 builds `zeros_like(xyz, requires_grad=True) + 0` and retains its gradient: a
     # tensor whose only purpose is to receive dL/dmeans2D in `.grad`.  A zero LEAF does that with one fill launch instead
     # of fill + add + the clone AddBackward makes for the retained gradient (the rasterizer never reads its values).
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # The leaf is a fresh tensor object over a cached all-zero storage nobody writes to (the gradient goes to `.grad`):
+    # no fill launch per frame.
+    screenspace_points = _zero_leaf(xyz)
     tanfovx = math.tan(data.FoVx * 0.5)
     tanfovy = math.tan(data.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
