@@ -387,6 +387,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wmax[16];
     __shared__ uint32_t wsum[16];
+    if (mode < 0) return;  // (the fill only: the caller uses an order it already has)
     tile_order_body<HELD>(ranges, keys, mode, ntiles, order, pc, ll, hist, wmax, wsum);
 }
 

@@ -24,6 +24,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_SHARED_QLIST].store(1);
     g_tune[GS_TUNE_ONES_FAST].store(1);
     g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
+    g_tune[GS_TUNE_BWD_ORDER].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -417,11 +418,13 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
         // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
+        const bool own_order = gs_tune_get(GS_TUNE_BWD_ORDER) != 0;
         { StageScope sc_("tile_order", s);
-        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, 1, I.gx * I.gy, order_b, PairCount{nullptr, 0},
+        rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, own_order ? 1 : -1, I.gx * I.gy, order_b, PairCount{nullptr, 0},
                                FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1},
                                LongLists{0, nullptr}, a->debug, s); }
         if (rc != GS_OK) return rc;
+        if (!own_order) order_b = (uint32_t*)(const_cast<char*>(im) + I.order);
         SecondImage si{nullptr, nullptr, nullptr, nullptr};
         if (second) {
             // the second render's own image state: its checkpoints (same chunk boundaries: same geometry, same rule)
@@ -691,6 +694,7 @@ int gs_tuning(const char* name, int value) {
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
+    if (strcmp(name, "bwd_order") == 0) { g_tune[GS_TUNE_BWD_ORDER].store(value); return GS_OK; }  // 0: the backward walks the tiles in the forward's launch order (A/B: + 12 us at config 3)
     if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix
     return GS_E_BAD_ARG;
 }

@@ -121,7 +121,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 // process-wide tuning switches (gs_tuning)
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_COUNT = 8 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_BWD_ORDER = 8, GS_TUNE_COUNT = 9 };
 int gs_tune_get(int key);
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     const int chunk = chunks > 1 ? (int)blockIdx.x / blocks_per_chunk : 0;
     render_block_map((int)blockIdx.x - chunk * blocks_per_chunk, xmap, &slot, &q);
     if (slot >= ntiles) return;
-    const int tile = (int)order[slot];  // heaviest tiles first (tile_order_kernel on the forward's counts)
+    const int tile = (int)(order[slot] & 0x7FFFFFFFu);  // heaviest tiles first (tile_order_kernel on the forward's counts; or the forward's own order, bit 31 = its mark)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int j = lane & (RING - 1), ring = lane / RING;  // position in the ring / which ring
