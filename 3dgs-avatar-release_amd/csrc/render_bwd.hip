@@ -62,28 +62,47 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
                                                  float gz, unsigned long long m1, uint32_t lds_addr, bwd_f4& q0, bwd_f4& q1,
                                                  bwd_f4& q2) {
     unsigned long long save;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_andn2_b64 exec, %[m1], %[m]\n\t"
-        "ds_read_b128 %[q0], %[a]\n\t"
-        "ds_read_b128 %[q1], %[a] offset:16\n\t"
-        "ds_read_b128 %[q2], %[a] offset:32\n\t"
-        "s_mov_b64 exec, %[m]\n\t"
-        "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"
-        "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"
-        "v_fmac_f32 %[x2], %[tdx], %[dx]\n\t"
-        "v_fmac_f32 %[x3], %[tdx], %[dy]\n\t"
-        "v_fmac_f32 %[x4], %[tdy], %[dy]\n\t"
-        "v_add_f32 %[x5], %[x5], %[Gd]\n\t"
-        "v_fmac_f32 %[x6], %[w], %[gx]\n\t"
-        "v_fmac_f32 %[x7], %[w], %[gy]\n\t"
-        "v_fmac_f32 %[x8], %[w], %[gz]\n\t"
+    // (SECOND: q2 = (b, r2, g2, b2), 16 bytes; otherwise only its first word is used: a 4-byte read, half the LDS cycles)
+#define GS_ACC_X                                     \
+        "s_mov_b64 exec, %[m]\n\t"                   \
+        "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"         \
+        "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"         \
+        "v_fmac_f32 %[x2], %[tdx], %[dx]\n\t"        \
+        "v_fmac_f32 %[x3], %[tdx], %[dy]\n\t"        \
+        "v_fmac_f32 %[x4], %[tdy], %[dy]\n\t"        \
+        "v_add_f32 %[x5], %[x5], %[Gd]\n\t"          \
+        "v_fmac_f32 %[x6], %[w], %[gx]\n\t"          \
+        "v_fmac_f32 %[x7], %[w], %[gy]\n\t"          \
+        "v_fmac_f32 %[x8], %[w], %[gz]\n\t"          \
         "s_mov_b64 exec, %[sv]"
-        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
-          [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [sv] "=&s"(save)
-        : [m] "s"(mask), [m1] "s"(m1), [a] "v"(lds_addr), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx),
-          [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
-        : "memory", "scc");
+#define GS_ACC_X_OUT [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), \
+                     [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [q0] "+v"(q0), [q1] "+v"(q1)
+#define GS_ACC_IN [m] "s"(mask), [m1] "s"(m1), [a] "v"(lds_addr), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), \
+                  [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
+    if constexpr (SECOND) {
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b128 %[q2], %[a] offset:32\n\t" GS_ACC_X
+            : GS_ACC_X_OUT, [q2] "+v"(q2), [sv] "=&s"(save)
+            : GS_ACC_IN
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b32 %[q2], %[a] offset:32\n\t" GS_ACC_X
+            : GS_ACC_X_OUT, [q2] "+v"(q2.x), [sv] "=&s"(save)
+            : GS_ACC_IN
+            : "memory", "scc");
+    }
+#undef GS_ACC_X
+#undef GS_ACC_X_OUT
+#undef GS_ACC_IN
     // (nothing may touch q0 / q1 / q2 between the two blocks: their loads are in flight.  The blocks are adjacent
     // statements; the second one names the registers as in / out operands, so it cannot be moved in front of a use.)
     asm volatile(
@@ -177,7 +196,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
     // wrap, and the rings RING_STRIDE = 48 words apart: the four rings' 16-word windows then fall into four
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
-    __shared__ float pix[OPA ? 7 : (SECOND ? 9 : 6)][4 * RING_STRIDE];  // (+ the opacity channel's gradient / the second image's)
+    // ... stored as PAIRS (one ds_read_b64 per pair: 2 LDS cycles for 8 bytes per lane where two ds_read_b32 take 4 -- with
+    // the entry switch done by LDS reads the kernel sits close to the LDS's cycle budget): (g0, g1) (g2, x) (y, lim)
+    // [+ (g4, -) / (h0, h1) (h2, -)]
+    constexpr int NP2 = OPA ? 4 : (SECOND ? 5 : 3);
+    __shared__ float2 pix[NP2][4 * RING_STRIDE];
     // the converted entries of a chunk, staged by ring 0 at a round start for the switch reads of the NEXT round
     __shared__ bwd_f4 ent[ENT_SLOTS][RING][3];
     int slot, q;
@@ -238,17 +261,13 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
             }
         }
         const int slot = ring * RING_STRIDE + j;
-        pix[0][slot] = pix[0][slot + RING] = c0.x;
-        pix[1][slot] = pix[1][slot + RING] = c0.y;
-        pix[2][slot] = pix[2][slot + RING] = c0.z;
-        pix[3][slot] = pix[3][slot + RING] = c1.x;
-        pix[4][slot] = pix[4][slot + RING] = c1.y;
-        pix[5][slot] = pix[5][slot + RING] = c1.z;
-        if (OPA) pix[6][slot] = pix[6][slot + RING] = c1.w;
+        pix[0][slot] = pix[0][slot + RING] = make_float2(c0.x, c0.y);
+        pix[1][slot] = pix[1][slot + RING] = make_float2(c0.z, c1.x);
+        pix[2][slot] = pix[2][slot + RING] = make_float2(c1.y, c1.z);
+        if (OPA) pix[3][slot] = pix[3][slot + RING] = make_float2(c1.w, 0.f);
         if (SECOND) {
-            pix[6][slot] = pix[6][slot + RING] = h.x;
-            pix[7][slot] = pix[7][slot + RING] = h.y;
-            pix[8][slot] = pix[8][slot + RING] = h.z;
+            pix[3][slot] = pix[3][slot + RING] = make_float2(h.x, h.y);
+            pix[4][slot] = pix[4][slot + RING] = make_float2(h.z, 0.f);
         }
         gtot0 = c0.w;
     }
@@ -300,10 +319,9 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
     uint32_t rowA = 0, rowB = 0;  // gradient rows of the entries the sets belong to
     // index into pix[c][] of the pixel at this lane: ring base + (s - j) mod 16, + 16 within a round
     uint32_t pidx = (uint32_t)(ring * RING_STRIDE + ((RING - j) & (RING - 1)));
-    constexpr int NPC = OPA ? 7 : (SECOND ? 9 : 6);
-    float pc[NPC];
+    float2 pc[NP2];
 #pragma unroll
-    for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
+    for (int c6 = 0; c6 < NP2; c6++) pc[c6] = pix[c6][pidx];
     // state of the pixel currently at this lane: transmittance and the part of Gtot not yet composited
     // (position i of a ring starts at ring lane (16 - i) mod 16; fetch its Gtot from the lane that loaded it)
     float T = __shfl(T0, ring * RING + ((RING - j) & (RING - 1)), 64);
@@ -352,15 +370,15 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict
         unsigned long long mx = 0x0001000100010001ull;  // ring positions <= t, kept up to date step by step
         auto step = [&](const int t) {
             const uint32_t s = (uint32_t)(s0 + t);
-            const float3 g = make_float3(pc[0], pc[1], pc[2]);  // dL/dpixel of the pixel at this lane
-            const float pxf = pc[3], pyf = pc[4];
-            const uint32_t lim = __float_as_uint(pc[5]);
-            const float g4 = OPA ? pc[6] : 0.f;
-            const float h0 = SECOND ? pc[6] : 0.f, h1 = SECOND ? pc[7] : 0.f, h2 = SECOND ? pc[8] : 0.f;
+            const float3 g = make_float3(pc[0].x, pc[0].y, pc[1].x);  // dL/dpixel of the pixel at this lane
+            const float pxf = pc[1].y, pyf = pc[2].x;
+            const uint32_t lim = __float_as_uint(pc[2].y);
+            const float g4 = OPA ? pc[3].x : 0.f;
+            const float h0 = SECOND ? pc[3].x : 0.f, h1 = SECOND ? pc[3].y : 0.f, h2 = SECOND ? pc[NP2 - 1].x : 0.f;
             // next step's pixel constants, fetched now
             pidx += 1u;
 #pragma unroll
-            for (int c6 = 0; c6 < NPC; c6++) pc[c6] = pix[c6][pidx];
+            for (int c6 = 0; c6 < NP2; c6++) pc[c6] = pix[c6][pidx];
             const float dx = cur.q0.x - pxf, dy = cur.q0.y - pyf;
             // A2 dx^2 + B2 dx dy + C2 dy^2 in five operations
             const float power2 = __builtin_fmaf(cur.q0.z * dx, dx, __builtin_fmaf(cur.q0.w, dx, cur.q1.x * dy) * dy);

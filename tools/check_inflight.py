@@ -32,9 +32,12 @@ def check(obj):
                 j += 1
             regs = set()
             k = i
-            while k < j and "ds_read_b128" in asm[k]:
+            while k < j and "ds_read_b" in asm[k]:  # the two or three reads of one switch (b128, b128, b128 | b32)
                 m = re.search(r"ds_read_b128 v\[(\d+):(\d+)\]", asm[k])
-                regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                if m:
+                    regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                else:
+                    regs.add(int(re.search(r"ds_read_b\d+ v(\d+)", asm[k]).group(1)))
                 k += 1
             for line in asm[k:j]:
                 ins = line.split("//")[0]
