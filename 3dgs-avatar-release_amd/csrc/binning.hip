@@ -224,12 +224,21 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
         }
     }
     __syncthreads();
-    // prefix down the columns (thread per column), then along the rows (a wave per row, 64 cells per trip)
-    for (int x = tid; x < ld; x += TC_THREADS) {
-        int acc = 0;
-        for (int y = 0; y < rows; y++) {
-            acc += grid[y * ld + x];
-            grid[y * ld + x] = acc;
+    // prefix down the columns (a wave per column, lanes = rows: one scan per 64 rows instead of a thread walking the
+    // column cell after cell), then along the rows (a wave per row, 64 cells per trip)
+    for (int x = wid; x < ld; x += (TC_THREADS / 64)) {
+        int carry = 0;
+        for (int y0 = 0; y0 < rows; y0 += 64) {
+            const int y = y0 + lane;
+            const int v = y < rows ? grid[y * ld + x] : 0;
+            int sc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(sc, d, 64);
+                if (lane >= d) sc += t;
+            }
+            if (y < rows) grid[y * ld + x] = carry + sc;
+            carry += __shfl(sc, 63, 64);
         }
     }
     __syncthreads();
