@@ -26,7 +26,9 @@ static inline size_t sort_table_words(size_t n) {
 }
 #define SCAN_ITEMS 2048          // elements per scan block (256 threads x 8)
 
+#ifndef DS_ITEMS
 #define DS_ITEMS 2048  // keys per workgroup in the counting / scattering passes of the bucket depth sort
+#endif
 #ifndef DS_PER_BUCKET
 #define DS_PER_BUCKET 64  // (128: config 3 - 0.5 %, a thin-shell cloud -- depths bunched at two surfaces -- - 2.4 %)
 #endif

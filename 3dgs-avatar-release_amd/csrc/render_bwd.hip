@@ -174,8 +174,11 @@ __device__ __forceinline__ void switch_entry(EntryQ& e, uint32_t lds_addr, unsig
 // obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
 // that channel: one more term in (c . g) and in Gtot, nothing else changes.
 // MODE 0: one image; 1 (OPA): + the opacity channel; 2 (SECOND): + a second image of the same geometry
+#ifndef BWD_MIN_WAVES
+#define BWD_MIN_WAVES 1
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64) void render_bwd_kernel(const float4* __restrict__ rec,
+__global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const float4* __restrict__ rec,
                                                         const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ order, int W, int H, int gx,
                                                         int ntiles, int xmap,
