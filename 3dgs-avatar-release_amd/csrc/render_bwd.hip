@@ -387,14 +387,12 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             const float power2 = __builtin_fmaf(cur.q0.z * dx, dx, __builtin_fmaf(cur.q0.w, dx, cur.q1.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
             const float al = fminf(0.99f, cur.q1.y * G);
-            // validity as VALU compare + select chains (no scalar mask arithmetic): the pair counts iff
-            // power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that has no
-            // entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's
-            // relaxed power2 >= thr pre-test).  Rejected pairs carry alpha = 0.
-            const float a1 = (power2 <= 0.0f) ? al : 0.f;
-            const float a2 = (s < lim) ? a1 : 0.f;
-            const bool valid = a2 >= (1.0f / 255.0f);
-            const float alpha = valid ? a2 : 0.f;
+            // The pair counts iff power <= 0, the entry lies before the pixel's last contributor (s < lim; a lane that
+            // has no entry yet holds zeros, i.e. alpha = 0), and alpha >= 1/255 (which implies the forward's relaxed
+            // power2 >= thr pre-test): three compares whose lane masks meet in two scalar ANDs, then one select each
+            // for alpha and G (rejected pairs carry alpha = 0).  (Until round 2: two selects more in place of the ANDs.)
+            const bool valid = (power2 <= 0.0f) && (s < lim) && (al >= (1.0f / 255.0f));
+            const float alpha = valid ? al : 0.f;
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
             float cg = cur.q1.z * g.x + cur.q1.w * g.y + cur.q2.x * g.z;

@@ -156,7 +156,8 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power2);
             const float al = fminf(0.99f, b.y * G);
-            const float a2 = (power2 <= 0.0f && al >= (1.0f / 255.0f)) ? al : 0.f;  // alpha, or 0 if the pair is rejected
+            const bool valid = power2 <= 0.0f && al >= (1.0f / 255.0f);
+            const float a2 = valid ? al : 0.f;                    // alpha, or 0 if the pair is rejected
             const float test_T = T * (1.f - a2);                  // == T for a rejected pair, < 0 for a frozen pixel
             const bool pass = test_T >= 0.0001f;
             const float wT = a2 * T;
@@ -165,7 +166,9 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
-            mark = (w > 0.f) ? (uint32_t)(uintptr_t)sp : mark;
+            // blended <=> w > 0 <=> valid and pass (pass implies T > 0): the AND of two lane masks the loop already has,
+            // one scalar instruction instead of a third compare
+            mark = (valid && pass) ? (uint32_t)(uintptr_t)sp : mark;
         };
         // The loop is software-pipelined by hand, two entries per trip: the LDS reads of the NEXT entry are issued
         // before the current one is evaluated.  With eight waves per SIMD the LDS latency hides behind the other waves
