@@ -6,6 +6,10 @@
 // chain with its compares / selects and the last-contributor mark are the product's; records, qlist, checkpoints and the
 // early exit are left out of both.  Mode 0: 16384 waves x E entries, 64 pixels each; mode 1: 8192 waves x UNION x E
 // entries, 128 pixels each -- the same image.   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o fwd_two_pixel.bin ...
+// Attribution builds (mode 0 line only): -DEXP_NOLDS = the loop without its LDS reads (every entry value made opaque per
+// iteration, or the compiler hoists half the blend chain and the run reads 91 us): 145 us against 136 -- the reads cost
+// nothing; -DEXP_NOB / -DEXP_NOC = without the second / third read: 133 / 140 us; -DEXP_NOEXP = without v_exp_f32: 125 us.
+// The loop is bound by its own instruction stream (24 VALU + 1 transcendental per entry: 56 issue cycles, 85 measured).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,7 +63,11 @@ __global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec,
             for (int p = 0; p < PIX; p++) {
                 const float dy = a.y - (pyf + 8.f * p);
                 const float power2 = __builtin_fmaf(adx, dx, __builtin_fmaf(a.w, dx, b.x * dy) * dy);
+#ifdef EXP_NOEXP
+                const float G = power2 * 0.001f + 0.01f;
+#else
                 const float G = __builtin_amdgcn_exp2f(power2);
+#endif
                 const float al = fminf(0.99f, b.y * G);
                 const bool valid = power2 <= 0.0f && al >= (1.0f / 255.0f);
                 const float a2 = valid ? al : 0.f;
@@ -75,15 +83,37 @@ __global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec,
             }
         };
         auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
+#ifdef EXP_NOB
+        auto ld_b = [&](int o) { return make_float2(-0.01f, 0.05f); };
+#else
         auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
+#endif
+#ifdef EXP_NOC
+        auto ld_c = [&](int o) { return make_float4(0.5f, 0.4f, 0.3f, 0.f); };
+#else
         auto ld_c = [&](int o) {
             const float4 c = *reinterpret_cast<const float4*>(sp + o + 32);
             asm volatile("" ::"v"(c.w));
             return c;
         };
+#endif
         float4 a0 = ld_a(0), c0 = ld_c(0);
         float2 b0 = ld_b(0);
         int j = 0;
+#ifdef EXP_NOLDS
+        const float4 a1 = ld_a(48), c1 = ld_c(48);
+        const float2 b1 = ld_b(48);
+        for (; j + 1 < cnt; j += 2) {  // (attribution run: the loop without its LDS reads)
+            // (every value opaque per iteration: nothing of the blend chain may be hoisted out of the loop)
+            asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(b0.x), "+v"(b0.y), "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(sp));
+            blend(a0, b0, c0);
+            sp += 96;
+            float4 a1v = a1, c1v = c1;
+            float2 b1v = b1;
+            asm volatile("" : "+v"(a1v.x), "+v"(a1v.y), "+v"(a1v.z), "+v"(a1v.w), "+v"(b1v.x), "+v"(b1v.y), "+v"(c1v.x), "+v"(c1v.y), "+v"(c1v.z));
+            blend(a1v, b1v, c1v);
+        }
+#else
         for (; j + 1 < cnt; j += 2) {
             const float4 a1 = ld_a(48), c1 = ld_c(48);
             const float2 b1 = ld_b(48);
@@ -92,6 +122,7 @@ __global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec,
             sp += 96;
             blend(a1, b1, c1);
         }
+#endif
         if (j < cnt) blend(a0, b0, c0);
     }
 #pragma unroll
