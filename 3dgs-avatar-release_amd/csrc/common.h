@@ -371,14 +371,14 @@ int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const flo
 // fills the array with 0xFF bytes) | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
 #define ROW_UNWRITTEN 0xFFFFFFFFu  // a NaN pattern no arithmetic produces
 // Row of (pair, quadrant): Gaussian i owns the 4 tt rows [4 first_pair, 4 (first_pair + tt)), tt = w h tiles of its
-// rectangle.  QUADRANT-MAJOR inside the span: row = 4 first_pair + q tt + (tile's index in the rectangle, y outer / x
-// inner) -- the four consecutive rows of a 128-byte line are then the SAME quadrant of four x-adjacent tiles, which a
-// Gaussian's footprint reaches together or not at all far more often than the four quadrants of one tile (a footprint
-// is about as large as a tile: most tiles of its rectangle are cut by its boundary), so the rows the backward writes
-// sit in fewer lines for segment_reduce_kernel to fetch.
-__host__ __device__ __forceinline__ uint32_t gradient_row(uint32_t first_pair, uint32_t w, uint32_t h, uint32_t tile_in_rect,
-                                                          uint32_t q) {
-    return first_pair * 4u + q * (w * h) + tile_in_rect;
+// rectangle, i.e. a grid of 2w x 2h quadrants.  The rows are laid out ROW-MAJOR OVER THAT QUADRANT GRID: row = 4 first_pair
+// + (2 ty + (q >> 1)) 2w + 2 tx + (q & 1) for the tile (tx, ty) of the rectangle.  A 128-byte line (four rows) is then four
+// horizontally adjacent quadrants -- a strip of 32 x 8 pixels -- which a Gaussian's footprint (about as large as a tile)
+// reaches together or not at all far more often than the four quadrants of one tile (most tiles of a rectangle are cut
+// by the footprint's boundary): the rows the backward writes sit in fewer lines for segment_reduce_kernel to fetch, and
+// two of a line's rows still come from the two quadrant waves of one tile (same XCD: the L2 merges their stores).
+__host__ __device__ __forceinline__ uint32_t gradient_row(uint32_t first_pair, uint32_t w, uint32_t tx, uint32_t ty, uint32_t q) {
+    return first_pair * 4u + (2u * ty + (q >> 1)) * (2u * w) + 2u * tx + (q & 1u);
 }
 static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 32, 256); }
 static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 4, 256); }

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
     float3 q2 = make_float3(0.f, 0.f, 0.f);  // (SECOND) the gathered entry's colour in the second image
     auto stage = [&](const float4 p0, const float4 p1, const float4 p2, const int chunk, uint32_t& row) {
         const uint32_t off = __float_as_uint(p2.y), rmin = __float_as_uint(p2.z), rsz = __float_as_uint(p2.w);
-        const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu, h = rsz >> 16;
-        row = gradient_row(off, w, h, ((uint32_t)ty - miny) * w + ((uint32_t)tx - minx), (uint32_t)q);
+        const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, w = rsz & 0xFFFFu;
+        row = gradient_row(off, w, (uint32_t)tx - minx, (uint32_t)ty - miny, (uint32_t)q);
         if (ring == 0) {
             bwd_f4* e = ent[chunk & (ENT_SLOTS - 1)][j];
             e[0] = bwd_f4{p0.x, p0.y, (-0.5f * LOG2E_F) * p0.z, -LOG2E_F * p0.w};
