@@ -334,7 +334,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
         not_ones = (gs_tune_get(GS_TUNE_ONES_FAST) && gs_tune_get(GS_TUNE_SHARED_QLIST) && a->colors_precomp && D > 0)
                        ? (unsigned long long*)(const_cast<char*>(gs) + L.count) + 2 : nullptr;
         rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
-                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, s);
+                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, (uint32_t*)(im + I.all_ones), s);
         if (rc != GS_OK) return rc;
     }
     // the new image state needs its own copy of the tile ranges and launch order (its backward reads them)
@@ -364,7 +364,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
         StageScope sc_("second_ones", s);
         rc = launch_second_ones(a->bg, a->W, a->H, ql, (const float*)(is + I.final_T), (const uint32_t*)(is + I.ncon_c),
                                 (const float4*)(is + I.ckpt), (const uint32_t*)(is + I.ck_start), out_color,
-                                (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), s);
+                                (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), (uint32_t*)(im + I.all_ones), s);
         if (rc != GS_OK) return rc;
     }
     if (a->debug) {
@@ -425,13 +425,14 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
                                LongLists{0, nullptr}, a->debug, s); }
         if (rc != GS_OK) return rc;
         if (!own_order) order_b = (uint32_t*)(const_cast<char*>(im) + I.order);
-        SecondImage si{nullptr, nullptr, nullptr, nullptr};
+        SecondImage si{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (second) {
             // the second render's own image state: its checkpoints (same chunk boundaries: same geometry, same rule)
             const ImgLayout I2 = img_layout(a->W, a->H, second->long_lists);
             if (second->img_bytes < I2.total || I2.bwd_chunks != I.bwd_chunks) return GS_E_BAD_ARG;
             si = SecondImage{second->colors, second->out_color, second->dL_dpix,
-                             ql.chunks > 1 ? (const float4*)((const char*)second->img + I2.ckpt) : nullptr};
+                             ql.chunks > 1 ? (const float4*)((const char*)second->img + I2.ckpt) : nullptr,
+                             (const uint32_t*)((const char*)second->img + I2.all_ones)};
         }
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,

@@ -142,7 +142,7 @@ int gs_tune_get(int key);
 #endif
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, tile_zero_bytes, ckpt, ck_start, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, all_ones, tile_zero_bytes, ckpt, ck_start, total;
     int gx, gy, bwd_chunks;
 };
 // `long_lists`: GsFwdArgs.long_lists (the few-long-lists machinery on an image of any size)
@@ -164,7 +164,11 @@ static inline ImgLayout img_layout(int W, int H, int long_lists = 0) {
     L.order = take(nt * 4);
     L.seg_cnt = take(nt * 4 * (size_t)bin_grid(L.gx, L.gy).nseg_max);  // [segment][tile] pair counts
     L.tile_tot = take(nt * 4);                     // pairs per tile
-    L.tile_zero_bytes = nt * 4;
+    // 1: this image is a second render of another call's geometry whose colours are all (1, 1, 1), written as 1 - T
+    // (second_ones_kernel); 0 for every other image (cleared with the totals by the preprocess kernel, or by
+    // recolor_kernel): the one-pass backward of both images then needs no colours of the second image at all
+    L.all_ones = take(4);
+    L.tile_zero_bytes = L.all_ones + 4 - L.tile_tot;
     L.bwd_chunks = few_long_lists_mode((int)nt, long_lists) ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
@@ -246,7 +250,8 @@ struct RankOut { const float* rec; const uint32_t* tiles; uint32_t* sorted_idx; 
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s);
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
-                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, hipStream_t s);
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, uint32_t* all_ones_init,
+                   hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
@@ -353,6 +358,7 @@ struct SecondImage {
     const float* out_color;  // [3,H,W] the second render
     const float* dL_dpix;    // [3,H,W]
     const float4* ckpt;      // its checkpoints (chunked backward), or null
+    const uint32_t* all_ones;  // a word of its image state: 1 = its colours are all (1, 1, 1) (ImgLayout.all_ones)
 };
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
@@ -360,7 +366,7 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
                            hipStream_t s);
 int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
                        const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
-                       uint32_t* n_contrib, hipStream_t s);
+                       uint32_t* n_contrib, uint32_t* all_ones, hipStream_t s);
 // opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,

@@ -187,8 +187,10 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
                                                       const uint32_t* __restrict__ tiles_src,
                                                       float4* __restrict__ rec_dst, uint32_t* __restrict__ tiles_dst,
                                                       uint32_t* __restrict__ clamped_dst,
-                                                      unsigned long long* __restrict__ not_ones) {
+                                                      unsigned long long* __restrict__ not_ones,
+                                                      uint32_t* __restrict__ all_ones_init) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && all_ones_init) *all_ones_init = 0u;  // (second_ones_kernel, behind this launch, sets it if it renders)
     if (i >= P) return;
     float4 r0 = rec_src[(size_t)i * 3], r1 = rec_src[(size_t)i * 3 + 1], r2 = rec_src[(size_t)i * 3 + 2];
     const uint32_t tt = tiles_src[i];
@@ -221,10 +223,11 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
 }
 
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
-                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, hipStream_t s) {
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, uint32_t* all_ones_init,
+                   hipStream_t s) {
     hipLaunchKernelGGL(recolor_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D, a.shs,
                        a.colors_precomp, a.campos, reinterpret_cast<const float4*>(rec_src), tiles_src,
-                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst, not_ones);
+                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst, not_ones, all_ones_init);
     GS_LAUNCH_CHECK("recolor", a.debug, s);
     return GS_OK;
 }

@@ -173,7 +173,11 @@ __device__ __forceinline__ void switch_entry(EntryQ& e, uint32_t lds_addr, unsig
 // OPA: the image has a fourth channel whose "colour" is 1 for every Gaussian -- the opacity render the reference
 // obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
 // that channel: one more term in (c . g) and in Gtot, nothing else changes.
-// MODE 0: one image; 1 (OPA): + the opacity channel; 2 (SECOND): + a second image of the same geometry
+// MODE 0: one image; 1 (OPA): + the opacity channel; 2 (SECOND): + a second image of the same geometry; 3 (SONES): + a
+// second image whose colours are all (1, 1, 1) -- the reference's opacity pass (gaussian_renderer/__init__.py:132-142):
+// its colour term is the same for every entry, (c2 . h) = h0 + h1 + h2 of the pixel, so the loop is MODE 1's (one add, no
+// second colours gathered, staged or read) with MODE 2's set-up.  Both 2 and 3 are launched for a second image; each
+// leaves at once unless the second image's `all_ones` word says it is its case (the host does not know).
 #ifndef BWD_MIN_WAVES
 #define BWD_MIN_WAVES 1
 #endif
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
                                                         const float4* __restrict__ ckpt,
                                                         const uint32_t* __restrict__ ck_start, const int chunks,
                                                         const int blocks_per_chunk, const SecondImage second) {
-    constexpr bool OPA = MODE == 1, SECOND = MODE == 2;
+    constexpr bool OPA = MODE == 1, SECOND = MODE == 2, SONES = MODE == 3;
+    if constexpr (SECOND) { if (*second.all_ones != 0u) return; }
+    if constexpr (SONES) { if (*second.all_ones == 0u) return; }
     // per-pixel constants, one array per component (adjacent lanes read adjacent words: no bank
     // conflicts; the 32-byte records this replaces cost 8-way conflicts on every step); ring r owns the
     // 16 pixels 16 r .. 16 r + 15, each ring's 16 values stored twice in a row so a round's reads never
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
     // ... stored as PAIRS (one ds_read_b64 per pair: 2 LDS cycles for 8 bytes per lane where two ds_read_b32 take 4 -- with
     // the entry switch done by LDS reads the kernel sits close to the LDS's cycle budget): (g0, g1) (g2, x) (y, lim)
     // [+ (g4, -) / (h0, h1) (h2, -)]
-    constexpr int NP2 = OPA ? 4 : (SECOND ? 5 : 3);
+    constexpr int NP2 = (OPA || SONES) ? 4 : (SECOND ? 5 : 3);
     __shared__ float2 pix[NP2][4 * RING_STRIDE];
     // the converted entries of a chunk, staged by ring 0 at a round start for the switch reads of the NEXT round
     __shared__ bwd_f4 ent[ENT_SLOTS][RING][3];
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
                 c1.w = dL_dopa[pid];
                 c0.w += ((1.0f - Tf) + Tf * bg[0]) * c1.w;  // the opacity channel's share of Gtot
             }
-            if (SECOND) {
+            if (SECOND || SONES) {
                 h = make_float3(second.dL_dpix[pid], second.dL_dpix[HW + pid], second.dL_dpix[2 * HW + pid]);
                 c0.w += second.out_color[pid] * h.x + second.out_color[HW + pid] * h.y + second.out_color[2 * HW + pid] * h.z;
             }
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
                 T0 = ck.x;
                 c0.w -= ck.y * g0 + ck.z * g1 + ck.w * g2;
                 if (OPA) c0.w -= (1.0f - ck.x) * c1.w;
-                if (SECOND) {
+                if (SECOND || SONES) {
                     const float4 ck2 = second.ckpt[ci];  // (the second render's own checkpoints: same T, its colours)
                     c0.w -= ck2.y * h.x + ck2.z * h.y + ck2.w * h.z;
                 }
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
         pix[1][slot] = pix[1][slot + RING] = make_float2(c0.z, c1.x);
         pix[2][slot] = pix[2][slot + RING] = make_float2(c1.y, c1.z);
         if (OPA) pix[3][slot] = pix[3][slot + RING] = make_float2(c1.w, 0.f);
+        if (SONES) pix[3][slot] = pix[3][slot + RING] = make_float2(h.x + h.y + h.z, 0.f);
         if (SECOND) {
             pix[3][slot] = pix[3][slot + RING] = make_float2(h.x, h.y);
             pix[4][slot] = pix[4][slot + RING] = make_float2(h.z, 0.f);
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             const float3 g = make_float3(pc[0].x, pc[0].y, pc[1].x);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[1].y, pyf = pc[2].x;
             const uint32_t lim = __float_as_uint(pc[2].y);
-            const float g4 = OPA ? pc[3].x : 0.f;
+            const float g4 = (OPA || SONES) ? pc[3].x : 0.f;
             const float h0 = SECOND ? pc[3].x : 0.f, h1 = SECOND ? pc[3].y : 0.f, h2 = SECOND ? pc[NP2 - 1].x : 0.f;
             // next step's pixel constants, fetched now
             pidx += 1u;
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
             float cg = cur.q1.z * g.x + cur.q1.w * g.y + cur.q2.x * g.z;
-            if constexpr (OPA) cg += g4;
+            if constexpr (OPA || SONES) cg += g4;
             if constexpr (SECOND) cg += cur.q2.y * h0 + cur.q2.z * h1 + cur.q2.w * h2;
             Rem = __builtin_fmaf(-cg, wgt, Rem);
             const float one_m = 1.f - alpha;
@@ -450,14 +457,15 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
     const int chunks = ql.ckpt ? ql.chunks : 1;
     const int bpc = render_grid_blocks(gx * gy, xmap);
     const dim3 grid((unsigned)bpc * (unsigned)chunks);
-    const SecondImage none{nullptr, nullptr, nullptr, nullptr};
+    const SecondImage none{nullptr, nullptr, nullptr, nullptr, nullptr};
 #define GS_BWD_ARGS                                                                                                       \
     reinterpret_cast<const float4*>(rec), reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, \
         ql.ncon_c, ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt,    \
         ql.ck_start, chunks, bpc
-    if (second)
-        hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);
-    else if (dL_dopa)
+    if (second) {
+        hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);  // (one of the two leaves at once)
+        hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);
+    } else if (dL_dopa)
         hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);
     else
         hipLaunchKernelGGL(render_bwd_kernel<0>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);

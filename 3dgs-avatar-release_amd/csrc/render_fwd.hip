@@ -579,11 +579,12 @@ struct SecondOnes {
     const float* src_final_T; const uint32_t* src_n_contrib; const uint32_t* src_ncon_c; const uint32_t* src_qcount;
     const float4* src_ckpt; const uint32_t* src_ck_start;
     float* out_color; float* final_T; uint32_t* n_contrib; uint32_t* ncon_c; uint32_t* qcount; float4* ckpt; uint32_t* ck_start;
-    const float* bg; const unsigned long long* not_ones; int W, H, gx, ntiles, chunks;
+    const float* bg; const unsigned long long* not_ones; int W, H, gx, ntiles, chunks; uint32_t* all_ones;
 };
 __global__ __launch_bounds__(64) void second_ones_kernel(const SecondOnes A) {
     if (*A.not_ones != 0ull) return;
     const int quad = blockIdx.x, tile = quad >> 2, q = quad & 3, lane = threadIdx.x;
+    if (quad == 0 && lane == 0 && A.all_ones) *A.all_ones = 1u;  // this image IS 1 - T: the one-pass backward may rely on it
     if (tile >= A.ntiles) return;
     const int tx = tile % A.gx, ty = tile / A.gx;
     const int px = tx * TILE + 8 * (q & 1) + (lane & 7), py = ty * TILE + 8 * (q >> 1) + (lane >> 3);
@@ -611,11 +612,11 @@ __global__ __launch_bounds__(64) void second_ones_kernel(const SecondOnes A) {
 
 int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
                        const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
-                       uint32_t* n_contrib, hipStream_t s) {
+                       uint32_t* n_contrib, uint32_t* all_ones, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int chunks = ql.ckpt ? ql.chunks : 1;
     const SecondOnes A{src_final_T, ql.src_n_contrib, src_ncon_c, ql.src_qcount, src_ckpt, src_ck_start, out_color, final_T,
-                       n_contrib, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start, bg, ql.not_ones, W, H, gx, gx * gy, chunks};
+                       n_contrib, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start, bg, ql.not_ones, W, H, gx, gx * gy, chunks, all_ones};
     hipLaunchKernelGGL(second_ones_kernel, dim3((unsigned)(gx * gy * 4)), dim3(64), 0, s, A);
     GS_LAUNCH_CHECK("second_ones", 0, s);
     return GS_OK;

@@ -174,7 +174,9 @@ int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const voi
  * second image adds one dot product per (pixel, Gaussian) step and one term to Gtot instead of a whole second backward.
  * The gradients are the SUM of both images' gradients w.r.t. the shared inputs; the second image's colours get none
  * (they must be constants); dL_dcolors / dL_dsh are the first image's.  `img` = the image state gs_forward_shared
- * filled for the second render (its checkpoints), `long_lists` the value that render was given. */
+ * filled for the second render (its checkpoints; a word of it says whether that render's colours were all (1, 1, 1), in
+ * which case the pass needs no second colours at all: the reference's case), `long_lists` the value that render was
+ * given. */
 typedef struct GsSecondImage {
     const float* colors;    /* [P,3] colors_precomp of the second render */
     const float* out_color; /* [3,H,W] its result */

@@ -930,6 +930,47 @@ def test_full_size_reference_step_two_images_default_path(oracle, monkeypatch, s
     _two_call_step(oracle, monkeypatch, scene, bg, mode, use)
 
 
+@pytest.mark.parametrize("layout,n,W,H", [("box", 6000, 208, 160), ("body", 30000, 256, 256)])
+def test_second_render_with_arbitrary_constant_colours_one_backward_for_both_images(oracle, monkeypatch, layout, n, W, H):
+    """The one-pass backward of two images of the same geometry (gs_backward_with_second) in its GENERAL form: the second
+    call's colours are arbitrary constants, not the reference's all-ones (for which the backward runs a cheaper kernel
+    that needs no second colours at all: the full-size two-call tests).  Both images and every gradient against the oracle's
+    two passes; on the body layout the lists are long enough for the chunked backward and its second set of checkpoints."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsplat_mi355 import _lib
+    dev = torch.device("cuda:0")
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=21, layout=layout, scale_mul=1.0 if layout == "body" else 1.3)
+    bg = (0.2, 0.1, 0.4)
+    gen = torch.Generator().manual_seed(5)
+    cols2 = torch.rand(n, 3, generator=gen)
+    g0, g1 = torch.randn(3, H, W, generator=gen), torch.randn(3, H, W, generator=gen)
+    counter = _CallCounter(_lib.load())
+    monkeypatch.setattr(_lib, "_lib", counter)
+    dgr.release_shared_geometry()
+    xyz = cloud.xyz.to(dev).requires_grad_(True)
+    m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
+    op = cloud.opacity.to(dev).requires_grad_(True)
+    cov = helpers.covariance6_cpu(cloud).to(dev).requires_grad_(True)
+    cols = helpers.precomp_colors(cloud, cam).to(dev).requires_grad_(True)
+    rast = GaussianRasterizer(_settings(cam, cloud, bg, dev))
+    img1, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=cols, cov3D_precomp=cov)
+    img2, _ = rast(means3D=xyz, means2D=m2d, opacities=op, colors_precomp=cols2.to(dev), cov3D_precomp=cov)
+    ((img1 * g0.to(dev)).sum() + (img2 * g1.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert counter.calls["gs_forward_shared"] == 1 and counter.calls["gs_backward_with_second"] == 1 and counter.calls["gs_backward"] == 0
+    sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode="precomp", cov_mode="cov")
+    sc2 = helpers.oracle_scene(cloud, cam, bg=bg, color_mode="precomp", colors=cols2, cov_mode="cov")
+    fw, fw2 = oracle.forward(sc), oracle.forward(sc2)
+    _bulk_close(img1.detach().cpu().numpy(), fw["color"], name="first image")
+    _bulk_close(img2.detach().cpu().numpy(), fw2["color"], name="second image")
+    b0, b1 = oracle.backward(sc, fw, g0.numpy()), oracle.backward(sc2, fw2, g1.numpy())
+    for k, t in (("means3D", xyz), ("means2D", m2d), ("opacities", op), ("cov3D_precomp", cov)):
+        w = b0[k].astype(np.float64) + b1[k]
+        _bulk_close(t.grad.cpu().numpy(), w.reshape(t.shape), tol=2e-5, frac=2e-4, name="two images: " + k, cap=GRAD_CAP)
+    _bulk_close(cols.grad.cpu().numpy(), b0["colors_precomp"], tol=2e-5, frac=2e-4, name="first image's colours", cap=GRAD_CAP)
+
+
 def test_heavy_tail_stress_config5_shape(oracle):
     """BASELINE config 5 in miniature: 5 % of the Gaussians with 4x scales (long per-tile lists, many
     64-entry chunks per quadrant), non-zero background, precomputed covariances."""
