@@ -334,13 +334,17 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
         not_ones = (gs_tune_get(GS_TUNE_ONES_FAST) && gs_tune_get(GS_TUNE_SHARED_QLIST) && a->colors_precomp && D > 0)
                        ? (unsigned long long*)(const_cast<char*>(gs) + L.count) + 2 : nullptr;
         rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
-                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, (uint32_t*)(im + I.all_ones), s);
+                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, (uint32_t*)(im + I.all_ones),
+                            CopyJob{(const uint32_t*)(is + I.ranges), (uint32_t*)(im + I.ranges), ntiles * 2},
+                            CopyJob{(const uint32_t*)(is + I.order), (uint32_t*)(im + I.order), ntiles}, s);
         if (rc != GS_OK) return rc;
+    } else {
+        // (no Gaussians: no recolouring launch to ride in) the new image state's own copy of the tile ranges and launch order
+        hipError_t e = hipMemcpyAsync(im + I.ranges, is + I.ranges, (size_t)ntiles * 8, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(im + I.order, is + I.order, (size_t)ntiles * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { gs_set_error((int)e, "shared.copy"); return GS_E_HIP; }
     }
-    // the new image state needs its own copy of the tile ranges and launch order (its backward reads them)
-    hipError_t e = hipMemcpyAsync(im + I.ranges, is + I.ranges, (size_t)ntiles * 8, hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(im + I.order, is + I.order, (size_t)ntiles * 4, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) { gs_set_error((int)e, "shared.copy"); return GS_E_HIP; }
+    hipError_t e = hipSuccess;
     const uint32_t* point_list = D > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
     QuadLists ql;
     ql.qlist = D > 0 ? (uint32_t*)(b + B.qlist) : nullptr;  // read, not rewritten: the recorded quadrant lists are what is walked

@@ -249,9 +249,11 @@ struct PairNumbering { const uint32_t *tiles, *wave_tiles; float* rec; unsigned 
 struct RankOut { const float* rec; const uint32_t* tiles; uint32_t* sorted_idx; uint4* ranklist; uint32_t* chunk_pairs; };
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s);
+// word ranges some kernel copies on the side (grid-stride), saving copy launches
+struct CopyJob { const uint32_t* src; uint32_t* dst; int words; };
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, uint32_t* all_ones_init,
-                   hipStream_t s);
+                   CopyJob c0, CopyJob c1, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between

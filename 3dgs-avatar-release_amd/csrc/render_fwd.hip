@@ -581,23 +581,27 @@ struct SecondOnes {
     float* out_color; float* final_T; uint32_t* n_contrib; uint32_t* ncon_c; uint32_t* qcount; float4* ckpt; uint32_t* ck_start;
     const float* bg; const unsigned long long* not_ones; int W, H, gx, ntiles, chunks; uint32_t* all_ones;
 };
-__global__ __launch_bounds__(64) void second_ones_kernel(const SecondOnes A) {
+__global__ __launch_bounds__(256) void second_ones_kernel(const SecondOnes A, const int pixel_blocks) {
     if (*A.not_ones != 0ull) return;
-    const int quad = blockIdx.x, tile = quad >> 2, q = quad & 3, lane = threadIdx.x;
-    if (quad == 0 && lane == 0 && A.all_ones) *A.all_ones = 1u;  // this image IS 1 - T: the one-pass backward may rely on it
-    if (tile >= A.ntiles) return;
-    const int tx = tile % A.gx, ty = tile / A.gx;
-    const int px = tx * TILE + 8 * (q & 1) + (lane & 7), py = ty * TILE + 8 * (q >> 1) + (lane >> 3);
-    if (px < A.W && py < A.H) {
-        const size_t HW = (size_t)A.H * A.W, pid = (size_t)py * A.W + px;
-        const float Tf = A.src_final_T[pid];
-        A.final_T[pid] = Tf;
-        A.n_contrib[pid] = A.src_n_contrib[pid];
-        A.ncon_c[pid] = A.src_ncon_c[pid];
-        A.out_color[pid] = (1.0f - Tf) + Tf * A.bg[0];
-        A.out_color[HW + pid] = (1.0f - Tf) + Tf * A.bg[1];
-        A.out_color[2 * HW + pid] = (1.0f - Tf) + Tf * A.bg[2];
+    if ((int)blockIdx.x < pixel_blocks) {
+        // the per-pixel part, in memory order: one pixel per thread, 256 consecutive pixels per workgroup (a wave per
+        // quadrant touches eight 32-byte runs per access: 1.4 TB/s)
+        const size_t HW = (size_t)A.H * A.W, pid = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && A.all_ones) *A.all_ones = 1u;  // this image IS 1 - T: the one-pass backward may rely on it
+        if (pid < HW) {
+            const float Tf = A.src_final_T[pid];
+            A.final_T[pid] = Tf;
+            A.n_contrib[pid] = A.src_n_contrib[pid];
+            A.ncon_c[pid] = A.src_ncon_c[pid];
+            A.out_color[pid] = (1.0f - Tf) + Tf * A.bg[0];
+            A.out_color[HW + pid] = (1.0f - Tf) + Tf * A.bg[1];
+            A.out_color[2 * HW + pid] = (1.0f - Tf) + Tf * A.bg[2];
+        }
+        return;
     }
+    // the per-quadrant records: a wave per quadrant
+    const int quad = ((int)blockIdx.x - pixel_blocks) * 4 + (threadIdx.x >> 6), tile = quad >> 2, lane = threadIdx.x & 63;
+    if (tile >= A.ntiles) return;
     if (lane == 0) A.qcount[quad] = A.src_qcount[quad];
     if (A.chunks > 1) {
         if (lane < A.chunks) A.ck_start[(size_t)quad * A.chunks + lane] = A.src_ck_start[(size_t)quad * A.chunks + lane];
@@ -617,7 +621,8 @@ int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const
     const int chunks = ql.ckpt ? ql.chunks : 1;
     const SecondOnes A{src_final_T, ql.src_n_contrib, src_ncon_c, ql.src_qcount, src_ckpt, src_ck_start, out_color, final_T,
                        n_contrib, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start, bg, ql.not_ones, W, H, gx, gx * gy, chunks, all_ones};
-    hipLaunchKernelGGL(second_ones_kernel, dim3((unsigned)(gx * gy * 4)), dim3(64), 0, s, A);
+    const int pixel_blocks = (int)(((size_t)W * H + 255) / 256);
+    hipLaunchKernelGGL(second_ones_kernel, dim3((unsigned)(pixel_blocks + gx * gy)), dim3(256), 0, s, A, pixel_blocks);
     GS_LAUNCH_CHECK("second_ones", 0, s);
     return GS_OK;
 }
