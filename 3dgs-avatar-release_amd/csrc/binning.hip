@@ -134,6 +134,13 @@ __device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int b
 // segments are contiguous runs of chunks (possibly empty).  Every workgroup derives the run of its segment itself: one
 // load of the chunk sums and a 1024-wide scan.  Returns the rank range [*r0, *r1) of segment sg.
 #define SEG_RANK_W 4096u
+// (the segment of a chunk with `before` work in front of it: floor(before * scale / 2^32), scale = floor(nseg * 2^32 / total)
+// -- non-decreasing in `before`, below nseg because before < total, and a multiply per chunk instead of a 64-bit division;
+// the counting and the writing pass cut the ranking with this same function, which is all that matters)
+__device__ __forceinline__ int segment_of(unsigned long long before, unsigned long long scale, int nseg) {
+    const unsigned long long hi = __umul64hi(before, scale), lo = before * scale;
+    return (int)min((unsigned long long)(nseg - 1), (hi << 32) | (lo >> 32));
+}
 __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
                                                unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -141,41 +148,48 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
     const int nchunks = (P + 255) / 256;
     const int per = (nchunks + nthreads - 1) / nthreads;  // consecutive chunks per thread
     const int c0 = tid * per;
+    // the thread's chunk sums, four loads in flight (kept when they are all it has: P <= 1024 * its workgroup's threads),
+    // and the one in front of them
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    const uint32_t w_prev = (c0 > 0 && c0 <= nchunks) ? chunk_pairs[c0 - 1] : 0u;
     unsigned long long mine = 0;
-    for (int k = 0; k < per; k++)
-        if (c0 + k < nchunks) mine += (unsigned long long)chunk_pairs[c0 + k] + SEG_RANK_W;
-    unsigned long long x = mine;
+    for (int k0 = 0; k0 < per; k0 += 4) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
+        for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) mine += w[k];
     }
+    const unsigned long long x = wave_scan_incl(mine);
     int* bounds = reinterpret_cast<int*>(scratch + 16);
     if (lane == 63) scratch[wid] = x;
     if (tid == 0) { bounds[0] = nchunks; bounds[1] = nchunks; }
     __syncthreads();
     unsigned long long woff = 0, total = 0;
-    for (int w = 0; w < nwaves; w++) {
-        const unsigned long long c = scratch[w];
-        woff += w < wid ? c : 0ull;
+    for (int wv = 0; wv < nwaves; wv++) {
+        const unsigned long long c = scratch[wv];
+        woff += wv < wid ? c : 0ull;
         total += c;
     }
+    const unsigned long long scale = ((unsigned long long)nseg << 32) / total;  // (total >= SEG_RANK_W: P > 0)
     unsigned long long before = woff + x - mine;  // work before this thread's first chunk
     int prev_seg = -1;  // segment of the chunk before this thread's first one
-    if (c0 > 0 && c0 <= nchunks) {
-        // (the previous chunk's "work before" is not known here, but its segment is < the first one of ours unless equal:
-        // recompute it from its own work)
-        const unsigned long long pw = (unsigned long long)chunk_pairs[c0 - 1] + SEG_RANK_W;
-        prev_seg = (int)min((unsigned long long)(nseg - 1), (before - pw) * (unsigned long long)nseg / total);
-    }
-    for (int k = 0; k < per; k++) {
-        const int c = c0 + k;
-        if (c >= nchunks) break;
-        const int sgc = (int)min((unsigned long long)(nseg - 1), before * (unsigned long long)nseg / total);
-        if (sgc >= sg && prev_seg < sg) bounds[0] = c;           // first chunk of segment sg or later
-        if (sgc >= sg + 1 && prev_seg < sg + 1) bounds[1] = c;   // first chunk past segment sg
-        prev_seg = sgc;
-        before += (unsigned long long)chunk_pairs[c] + SEG_RANK_W;
+    if (c0 > 0 && c0 <= nchunks) prev_seg = segment_of(before - ((unsigned long long)w_prev + SEG_RANK_W), scale, nseg);
+    for (int k0 = 0; k0 < per; k0 += 4) {
+        if (per > 4) {  // (workgroup-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = c0 + k0 + k;
+            if (k0 + k < per && c < nchunks) {
+                const int sgc = segment_of(before, scale, nseg);
+                if (sgc >= sg && prev_seg < sg) bounds[0] = c;           // first chunk of segment sg or later
+                if (sgc >= sg + 1 && prev_seg < sg + 1) bounds[1] = c;   // first chunk past segment sg
+                prev_seg = sgc;
+                before += w[k];
+            }
+        }
     }
     __syncthreads();
     *r0 = min(P, bounds[0] * 256);
@@ -231,14 +245,9 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
         for (int y0 = 0; y0 < rows; y0 += 64) {
             const int y = y0 + lane;
             const int v = y < rows ? grid[y * ld + x] : 0;
-            int sc = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(sc, d, 64);
-                if (lane >= d) sc += t;
-            }
+            const int sc = (int)wave_scan_incl((uint32_t)v);
             if (y < rows) grid[y * ld + x] = carry + sc;
-            carry += __shfl(sc, 63, 64);
+            carry += __builtin_amdgcn_readlane(sc, 63);
         }
     }
     __syncthreads();
@@ -247,12 +256,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
         for (int x0 = 0; x0 < gx; x0 += 64) {
             const int x = x0 + lane;
             const int v = x < gx ? grid[y * ld + x] : 0;
-            int s = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(s, d, 64);
-                if (lane >= d) s += t;
-            }
+            const int s = (int)wave_scan_incl((uint32_t)v);
             const uint32_t c = x < gx ? (uint32_t)(carry + s) : 0u;
             const int t0 = (y0b + y) * gx + x0;  // lane 0's tile (wave-uniform)
             if (x < gx) seg_cnt[(size_t)sg * ntiles + (size_t)(t0 + lane)] = c;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
             // 256-byte atomic instruction per wave and trip; measured free next to the kernel's 12 us.  Sums per group of
             // tiles added the same way by one lane cost 6 us: 48 workgroups hitting the same word at the same moment)
             if (c) atomicAdd(&tile_tot[t0 + lane], c);
-            carry += __shfl(s, 63, 64);
+            carry += __builtin_amdgcn_readlane(s, 63);
         }
     }
 }
@@ -300,8 +304,7 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
     } else {
         for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    mx = wave_max(mx);
     if (lane == 0) wmax[wid] = mx;
     __syncthreads();
     mx = 0;
@@ -320,12 +323,7 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
     __syncthreads();
     // exclusive scan of the 1024 bins
     const uint32_t v = hist[tid];
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
+    const uint32_t x = wave_scan_incl(v);
     if (lane == 63) wsum[wid] = x;
     __syncthreads();
     uint32_t woff = 0;
@@ -351,8 +349,7 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
             } else {
                 for (int t = tid; t < ntiles; t += 1024) nlong += tile_work(ranges, keys, mode, t) > wide_from ? 1u : 0u;
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) nlong += (uint32_t)__shfl_xor((int)nlong, d, 64);
+            nlong = wave_sum(nlong);
             __syncthreads();  // (wsum is free again: the scan above has read it)
             if (lane == 0) wsum[wid] = nlong;
             __syncthreads();
@@ -444,7 +441,12 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     {
         const int t_blk0 = by0 * gx + bx0;
         uint32_t part = 0;
-        for (int t = tid; t < t_blk0; t += TBK_THREADS) part += tile_tot[t];
+        for (int t0 = 0; t0 < t_blk0; t0 += 4 * TBK_THREADS) {  // (four loads in flight)
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = t0 + k * TBK_THREADS + tid < t_blk0 ? tile_tot[t0 + k * TBK_THREADS + tid] : 0u;
+            part += (v[0] + v[1]) + (v[2] + v[3]);
+        }
         const int ty = by0 + wid, tx = bx0 + lane;
         const bool row_ok = tid < TB_TILES && ty < by1;  // (wave-uniform)
         const int t_row0 = ty * gx + bx0, t = t_row0 + lane;
@@ -464,11 +466,8 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
                 }
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            part += __shfl_xor(part, d, 64);
-            rowsum += __shfl_xor(rowsum, d, 64);
-        }
+        part = wave_sum(part);
+        rowsum = wave_sum(rowsum);
         uint32_t* s_part = reinterpret_cast<uint32_t*>(sb_scratch);  // 16 partial sums + 4 row sums (free until segment_bounds)
         if (lane == 0) {
             s_part[wid] = part;
@@ -479,12 +478,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             uint32_t before = 0;
             for (int w = 0; w < TBK_WAVES; w++) before += s_part[w];
             for (int r = 0; r < wid; r++) before += s_part[16 + r];
-            uint32_t x = tot;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= d) x += y;
-            }
+            const uint32_t x = wave_scan_incl(tot);
             const uint32_t first = before + x - tot;
             if (sg == 0 && tile_ok) ranges[t] = fits ? make_uint2(first, first + tot) : make_uint2(0u, 0u);
             my_dst = first + pre;
@@ -538,13 +532,14 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             if (gl < nw) { bits0 = bitmap[lt * BM_LD + gl]; bitmap[lt * BM_LD + gl] = 0u; }
             if (gl + 16 < nw) { bits1 = bitmap[lt * BM_LD + gl + 16]; bitmap[lt * BM_LD + gl + 16] = 0u; }
             const uint32_t c0 = (uint32_t)__popc(bits0), c1 = (uint32_t)__popc(bits1);
-            uint32_t x0 = c0, x1 = c1;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const uint32_t y0 = __shfl_up(x0, d, 16), y1 = __shfl_up(x1, d, 16);
-                if (gl >= d) { x0 += y0; x1 += y1; }
-            }
-            const uint32_t tot0 = __shfl(x0, 15, 16), tot1 = __shfl(x1, 15, 16);
+            // both prefix sums in one 16-lane DPP ladder (c0 | c1 << 16: a group's 16 words hold at most 512 bits), the
+            // groups' totals by four lane reads -- no trip through the LDS unit's cross-lane path
+            const uint32_t xs = row_scan_incl(c0 | (c1 << 16));
+            const uint32_t x0 = xs & 0xFFFFu, x1 = xs >> 16;
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 15), e1 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 31);
+            const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 47), e3 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
+            const uint32_t ends = grp == 0 ? e0 : (grp == 1 ? e1 : (grp == 2 ? e2 : e3));
+            const uint32_t tot0 = ends & 0xFFFFu, tot1 = ends >> 16;
             const uint32_t d0 = dst[lt];
             uint32_t pos = d0 + x0 - c0;
             while (bits0) {

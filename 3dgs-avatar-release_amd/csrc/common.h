@@ -40,7 +40,7 @@ static inline int ds_buckets(int P) {
 
 struct GeomLayout {
     size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, wkmin, wkmax, hist, count,
-        ds_tmp, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, total;
+        ds_tmp, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, ds_big, total;
     int nblk_sort, nwaves, ds_nb, ds_blocks;
 };
 static inline GeomLayout geom_layout(int P) {
@@ -74,7 +74,8 @@ static inline GeomLayout geom_layout(int P) {
     L.ds_tot = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_loc = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_grp = take((size_t)((L.ds_nb + 1 + 63) / 64) * 4);
-    L.ds_range = take(16);
+    L.ds_range = take(16);                                         // key range (3 words) + the number of large buckets
+    L.ds_big = take((size_t)(L.ds_nb + 1) * 4);                    // the buckets too large for a wave, in any order
     L.total = o;
     return L;
 }
@@ -195,6 +196,59 @@ void gs_prof_begin(const char* stage, hipStream_t s);
 void gs_prof_end(hipStream_t s);
 // a word range some kernel clears on the side (grid-stride), saving a fill launch
 struct ZeroJob { uint32_t* ptr; int words; };
+// Inclusive prefix sum over the 64 lanes of a wave by DPP row shifts and row broadcasts (six dependent VALU instructions;
+// a __shfl_up ladder is six ds_bpermute round trips through the LDS unit, ~10 x the latency -- and the short binning
+// kernels are nothing but latency).  Every lane must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += dpp_or_zero<0x111, 0xF>(x);  // row_shr:1
+    x += dpp_or_zero<0x112, 0xF>(x);  // row_shr:2
+    x += dpp_or_zero<0x114, 0xF>(x);  // row_shr:4
+    x += dpp_or_zero<0x118, 0xF>(x);  // row_shr:8
+    x += dpp_or_zero<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+    x += dpp_or_zero<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// the same inside every row of 16 lanes
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t x) {
+    x += dpp_or_zero<0x111, 0xF>(x);
+    x += dpp_or_zero<0x112, 0xF>(x);
+    x += dpp_or_zero<0x114, 0xF>(x);
+    x += dpp_or_zero<0x118, 0xF>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_scan_incl(unsigned long long x) {
+    // (two 32-bit ladders would lose the carries: shift the halves, add as 64-bit)
+#define GS_SCAN64_STEP(CTRL, MASK)                                                                           \
+    x += (unsigned long long)dpp_or_zero<CTRL, MASK>((uint32_t)x) |                                          \
+         ((unsigned long long)dpp_or_zero<CTRL, MASK>((uint32_t)(x >> 32)) << 32);
+    GS_SCAN64_STEP(0x111, 0xF) GS_SCAN64_STEP(0x112, 0xF) GS_SCAN64_STEP(0x114, 0xF) GS_SCAN64_STEP(0x118, 0xF)
+    GS_SCAN64_STEP(0x142, 0xA) GS_SCAN64_STEP(0x143, 0xC)
+#undef GS_SCAN64_STEP
+    return x;
+}
+
+// Wave-wide sum / max / min by the same ladder (the result is wave-uniform: lane 63 of the inclusive scan).
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(x), 63); }
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long x) {
+    x = wave_scan_incl(x);
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+    x = max(x, dpp_or_zero<0x111, 0xF>(x));
+    x = max(x, dpp_or_zero<0x112, 0xF>(x));
+    x = max(x, dpp_or_zero<0x114, 0xF>(x));
+    x = max(x, dpp_or_zero<0x118, 0xF>(x));
+    x = max(x, dpp_or_zero<0x142, 0xA>(x));
+    x = max(x, dpp_or_zero<0x143, 0xC>(x));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) { return ~wave_max(~x); }
+
 __device__ __forceinline__ void zero_job(const ZeroJob z) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;
 }
@@ -242,7 +296,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
                       uint32_t* wave_kmax, ZeroJob zero, ZeroJob zero2, hipStream_t s);
 // bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
-struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range; int nb, blocks; };
+struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range, *big; int nb, blocks; };
 // pair numbering done by the sort's first launch (see first_pair_kernel, which the radix path uses) and the rank list
 // written by its last ones (see rank_list_kernel, likewise)
 struct PairNumbering { const uint32_t *tiles, *wave_tiles; float* rec; unsigned long long *count, *host_count; uint32_t* chunk_pairs; int nchunks; };

@@ -15,204 +15,223 @@
 
 #define DS_THREADS 256
 #define DS_CAP_BIG 16384   // composites a 256-thread workgroup sorts in LDS (128 KB): second launch, for unevenly spread depths
+#define DS_WAVE_CAP 1024   // composites one wave sorts in LDS: the first launch
 
-__device__ __forceinline__ uint32_t ds_bucket_of(uint32_t key, uint32_t kmin, unsigned long long span, int nb) {
-    // span = kmax - kmin + 1 (>= 1); keys outside [kmin, kmax] only for Gaussians that touch no tile (0xFFFFFFFF)
+// Bucket of a key: floor((key - kmin) * scale / 2^32) with scale = floor(nb * 2^32 / span), span = kmax - kmin + 1 -- a
+// non-decreasing map of [kmin, kmax] onto [0, nb) that costs a 32 x 64-bit multiply per key (the exact quotient
+// (key - kmin) * nb / span is a 64-bit division per key: ~3 us of the counting and of the scattering pass each).
+// (key - kmin) < span, so the product stays below nb * 2^32.  Keys outside [kmin, kmax] only for Gaussians that touch
+// no tile (0xFFFFFFFF): bucket nb.
+__device__ __forceinline__ unsigned long long ds_bucket_scale(unsigned long long span, int nb) {
+    return ((unsigned long long)nb << 32) / span;  // span >= 1
+}
+__device__ __forceinline__ uint32_t ds_bucket_of(uint32_t key, uint32_t kmin, unsigned long long scale, int nb) {
     if (key == 0xFFFFFFFFu || key < kmin) return (uint32_t)nb;
-    const unsigned long long b = (unsigned long long)(key - kmin) * (unsigned long long)nb / span;
-    return b < (unsigned long long)nb ? (uint32_t)b : (uint32_t)(nb - 1);
+    const uint32_t d = key - kmin;
+    const uint32_t lo = (uint32_t)scale, hi = (uint32_t)(scale >> 32);
+    const uint32_t b = __umulhi(d, lo) + d * hi;  // (d * scale) >> 32 < nb: no carry out of the low word is lost
+    return b < (uint32_t)nb ? b : (uint32_t)(nb - 1);
 }
 
-// the frame's key range from the preprocess waves' partial ranges (every workgroup reduces them itself: a few KB)
-__device__ __forceinline__ void ds_key_range(const uint32_t* __restrict__ wave_kmin, const uint32_t* __restrict__ wave_kmax,
-                                             int nwaves, uint32_t* s_red /* LDS: 8 words */, uint32_t* kmin,
-                                             unsigned long long* span) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (int w = tid; w < nwaves; w += DS_THREADS) {
-        lo = min(lo, wave_kmin[w]);
-        hi = max(hi, wave_kmax[w]);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
-    }
-    if (lane == 0) { s_red[wid] = lo; s_red[4 + wid] = hi; }
-    __syncthreads();
-    lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-    __syncthreads();
-    *kmin = lo;
-    *span = hi >= lo ? (unsigned long long)(hi - lo) + 1ull : 1ull;  // (no keyed Gaussian at all: everything goes to bucket nb)
-}
-
-// The same launch numbers the pairs (binning.hip, "Pair numbering": first_pair = exclusive prefix sum of tiles_touched in
-// INDEX order, from the per-wave sums the preprocess kernel left; a workgroup's 2048 Gaussians are 32 of those waves) and
-// delivers the frame's pair count, and clears the per-chunk pair sums the bucket kernels add to.
+// The counting pass.  The same launch numbers the pairs (binning.hip, "Pair numbering": first_pair = exclusive prefix sum of
+// tiles_touched in INDEX order, from the per-wave sums the preprocess kernel left; a workgroup's 2048 Gaussians are 32 of
+// those waves), delivers the frame's pair count, and clears the per-chunk pair sums the bucket kernels add to.
+// Every workgroup reduces the preprocess waves' key ranges and the pair sums of the waves before it by itself (a few KB).
+// The kernel is a chain of memory round trips and nothing else, so everything a thread reads is requested before anything
+// is waited for: its keys and tile counts, then the per-wave words in trips of 16 x 3 loads.
+#define DS_WAVE_WORDS 16
 __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ wave_kmin,
                                                               const uint32_t* __restrict__ wave_kmax, int nwaves, int P,
                                                               int nb, uint32_t* __restrict__ cnt,
                                                               uint32_t* __restrict__ krange, const PairNumbering pn) {
-    extern __shared__ uint32_t s_hist[];  // nb + 1 counters + 8 words
-    uint32_t* s_red = s_hist + nb + 1;
-    const int tid = threadIdx.x;
-    {
-        __shared__ unsigned long long s_before[DS_THREADS / 64];
-        __shared__ uint32_t s_wave[DS_ITEMS / 64 + 1];  // exclusive prefix of this workgroup's wave sums, + their total
-        const int lane = tid & 63, wid = tid >> 6;
-        constexpr int WPB = DS_ITEMS / 64;  // preprocess waves per workgroup of this launch
-        const int w0 = WPB * (int)blockIdx.x;
-        for (int c = blockIdx.x * DS_THREADS + tid; c < pn.nchunks; c += gridDim.x * DS_THREADS) pn.chunk_pairs[c] = 0u;
-        unsigned long long before = 0;  // 64-bit: overflow of the 32-bit index space stays detectable in the count
-        for (int w = tid; w < w0; w += DS_THREADS) before += pn.wave_tiles[w];
+    extern __shared__ uint32_t s_hist[];  // nb + 1 counters
+    __shared__ uint32_t s_red[8];
+    __shared__ unsigned long long s_before[DS_THREADS / 64];
+    __shared__ uint32_t s_wave[DS_ITEMS / 64 + 1];  // exclusive prefix of this workgroup's wave sums, + their total
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int WPB = DS_ITEMS / 64;  // preprocess waves per workgroup of this launch
+    constexpr int NU = DS_ITEMS / DS_THREADS;
+    static_assert(WPB <= 64, "one wave scans the workgroup's wave sums");
+    static_assert(DS_THREADS == 256, "four partial sums");
+    const int w0 = WPB * (int)blockIdx.x;
+    const uint32_t* __restrict__ tiles = pn.tiles;
+    const uint32_t* __restrict__ wave_tiles = pn.wave_tiles;
+    uint32_t k[NU], tv[NU];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-        if (lane == 0) s_before[wid] = before;
-        if (wid == 0) {
-            static_assert(WPB <= 64, "one wave scans the workgroup's wave sums");
-            const uint32_t v = (lane < WPB && w0 + lane < nwaves) ? pn.wave_tiles[w0 + lane] : 0u;
-            uint32_t x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= d) x += y;
-            }
-            if (lane < WPB) s_wave[lane] = x - v;
-            if (lane == 63) s_wave[WPB] = x;
-        }
-        __syncthreads();
-        const unsigned long long block_base = (s_before[0] + s_before[1]) + (s_before[2] + s_before[3]);
-        static_assert(DS_THREADS == 256, "four partial sums");
-#pragma unroll
-        for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
-            const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
-            const uint32_t v = i < P ? pn.tiles[i] : 0u;
-            uint32_t x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= d) x += y;
-            }
-            if (i < P) pn.rec[(size_t)i * REC_F + 9] = __uint_as_float((uint32_t)block_base + s_wave[u * (DS_THREADS / 64) + wid] + x - v);
-        }
-        if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-            const unsigned long long total = block_base + s_wave[WPB];
-            pn.count[0] = total;
-            pn.count[2] = 0ull;  // "a second render's colours are not all ones" (recolor_kernel), for that render's use
-            // ... and straight into the caller's pinned host word, which the host is polling: the pair count
-            // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
-            if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the host reads this word only: no release -- a system-scope release writes the L2 back)
-        }
-    }
-    uint32_t k[DS_ITEMS / DS_THREADS];
-#pragma unroll
-    for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
+    for (int u = 0; u < NU; u++) {
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
         k[u] = i < P ? keys[i] : 0u;
+        tv[u] = i < P ? tiles[i] : 0u;
     }
+    const uint32_t own = (wid == 0 && lane < WPB && w0 + lane < nwaves) ? wave_tiles[w0 + lane] : 0u;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    unsigned long long before = 0;  // 64-bit: overflow of the 32-bit index space stays detectable in the count
+    for (int base = 0; base < nwaves; base += DS_THREADS * DS_WAVE_WORDS) {
+        uint32_t a[DS_WAVE_WORDS], c[DS_WAVE_WORDS], t[DS_WAVE_WORDS];
+#pragma unroll
+        for (int u = 0; u < DS_WAVE_WORDS; u++) {
+            const int w = base + u * DS_THREADS + tid;
+            a[u] = w < nwaves ? wave_kmin[w] : 0xFFFFFFFFu;
+            c[u] = w < nwaves ? wave_kmax[w] : 0u;
+            t[u] = w < w0 ? wave_tiles[w] : 0u;  // (w0 <= nwaves)
+        }
+#pragma unroll
+        for (int u = 0; u < DS_WAVE_WORDS; u++) {
+            lo = min(lo, a[u]);
+            hi = max(hi, c[u]);
+            before += t[u];
+        }
+    }
+    for (int c = blockIdx.x * DS_THREADS + tid; c < pn.nchunks; c += gridDim.x * DS_THREADS) pn.chunk_pairs[c] = 0u;
     for (int b = tid; b <= nb; b += DS_THREADS) s_hist[b] = 0u;
-    uint32_t kmin;
-    unsigned long long span;
-    ds_key_range(wave_kmin, wave_kmax, nwaves, s_red, &kmin, &span);  // (its barriers also cover the zeroing)
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    before = wave_sum(before);
+    if (lane == 0) { s_red[wid] = lo; s_red[4 + wid] = hi; s_before[wid] = before; }
+    if (wid == 0) {
+        const uint32_t x = wave_scan_incl(own);
+        if (lane < WPB) s_wave[lane] = x - own;
+        if (lane == 63) s_wave[WPB] = x;
+    }
+    __syncthreads();
+    // the frame's key range; keys outside it only for Gaussians that touch no tile
+    const uint32_t kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    const uint32_t kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const unsigned long long span = kmax >= kmin ? (unsigned long long)(kmax - kmin) + 1ull : 1ull;  // (no keyed Gaussian at all: everything goes to bucket nb)
+    const unsigned long long block_base = (s_before[0] + s_before[1]) + (s_before[2] + s_before[3]);
+    const unsigned long long scale = ds_bucket_scale(span, nb);  // (one division per thread instead of one per key)
     if (blockIdx.x == 0 && tid == 0) {  // for the scattering pass: it need not reduce the waves' ranges again
         krange[0] = kmin;
-        krange[1] = (uint32_t)span;
-        krange[2] = (uint32_t)(span >> 32);
+        krange[1] = (uint32_t)scale;
+        krange[2] = (uint32_t)(scale >> 32);
+        krange[3] = 0u;  // large buckets found by the prefix pass
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const unsigned long long total = block_base + s_wave[WPB];
+        pn.count[0] = total;
+        pn.count[2] = 0ull;  // "a second render's colours are not all ones" (recolor_kernel), for that render's use
+        // ... and straight into the caller's pinned host word, which the host is polling: the pair count
+        // reaches the CPU a PCIe write after it exists instead of after a copy + stream-sync wake-up
+        if (pn.host_count) __hip_atomic_store(pn.host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the host reads this word only: no release -- a system-scope release writes the L2 back)
     }
 #pragma unroll
-    for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
+    for (int u = 0; u < NU; u++) {
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
-        if (i < P) atomicAdd(&s_hist[ds_bucket_of(k[u], kmin, span, nb)], 1u);
+        const uint32_t x = wave_scan_incl(tv[u]);
+        if (i < P) {
+            pn.rec[(size_t)i * REC_F + 9] = __uint_as_float((uint32_t)block_base + s_wave[u * (DS_THREADS / 64) + wid] + x - tv[u]);
+            atomicAdd(&s_hist[ds_bucket_of(k[u], kmin, scale, nb)], 1u);
+        }
     }
     __syncthreads();
     for (int b = tid; b <= nb; b += DS_THREADS) cnt[(size_t)blockIdx.x * (nb + 1) + b] = s_hist[b];
 }
 
-// One wave per group of 64 buckets.  Per bucket: the workgroups' counts -> their exclusive prefix (in place) and the
-// bucket's total; per group: the buckets' exclusive prefix inside the group and the group's total.
-__global__ __launch_bounds__(64) void ds_prefix_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ pre,
-                                                       uint32_t* __restrict__ tot, uint32_t* __restrict__ loc,
-                                                       uint32_t* __restrict__ grp, int nbp, int blocks) {
-    const int lane = threadIdx.x;
+// One workgroup per group of 64 buckets (lane = bucket), its four waves a quarter of the counting workgroups each.  Per
+// bucket: the counting workgroups' counts -> their exclusive prefix and the bucket's total; per group: the buckets'
+// exclusive prefix inside the group and the group's total.  A wave has up to DSP_ROWS loads in flight; with at most
+// 4 x DSP_ROWS counting workgroups (P <= 262144) every count is loaded once, in one trip.
+#define DSP_ROWS 32
+__global__ __launch_bounds__(256) void ds_prefix_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ pre,
+                                                        uint32_t* __restrict__ tot, uint32_t* __restrict__ loc,
+                                                        uint32_t* __restrict__ grp, uint32_t* __restrict__ nbig,
+                                                        uint32_t* __restrict__ big, int nbp, int blocks) {
+    __shared__ uint32_t s_part[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + lane;
-    uint32_t acc = 0;
-    if (b < nbp) {
-        // (input and output are different arrays: the loads of all trips can be in flight together)
-        for (int g0 = 0; g0 < blocks; g0 += 16) {
-            uint32_t v[16];
+    const bool live = b < nbp;
+    const int per = (blocks + 3) >> 2, r0 = wid * per, r1 = min(blocks, r0 + per);
+    const bool one_trip = per <= DSP_ROWS;  // (workgroup-uniform)
+    uint32_t v[DSP_ROWS];
+    uint32_t sum = 0;
+    for (int g0 = r0; g0 < r1; g0 += DSP_ROWS) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = (g0 + u < blocks) ? cnt[(size_t)(g0 + u) * nbp + b] : 0u;
+        for (int u = 0; u < DSP_ROWS; u++) v[u] = (live && g0 + u < r1) ? cnt[(size_t)(g0 + u) * nbp + b] : 0u;
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                if (g0 + u < blocks) pre[(size_t)(g0 + u) * nbp + b] = acc;
-                acc += v[u];
-            }
+        for (int u = 0; u < DSP_ROWS; u++) sum += v[u];
+    }
+    s_part[wid][lane] = sum;
+    __syncthreads();
+    uint32_t acc = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t q = s_part[w][lane];
+        if (w < wid) acc += q;
+        total += q;
+    }
+    for (int g0 = r0; g0 < r1; g0 += DSP_ROWS) {
+        if (!one_trip) {
+#pragma unroll
+            for (int u = 0; u < DSP_ROWS; u++) v[u] = (live && g0 + u < r1) ? cnt[(size_t)(g0 + u) * nbp + b] : 0u;
         }
-        tot[b] = acc;
-    }
-    uint32_t x = acc;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (b < nbp) loc[b] = x - acc;
-    if (lane == 63) grp[blockIdx.x] = x;
-}
-
-// first slot of every bucket into LDS (s_base[0 .. nbp]): group sums scanned by the first wave, + the in-group prefix
-__device__ __forceinline__ void ds_bucket_bases(const uint32_t* __restrict__ loc, const uint32_t* __restrict__ grp, int nbp,
-                                                uint32_t* s_grp /* LDS: 65 words */, uint32_t* s_base) {
-    const int tid = threadIdx.x;
-    const int ngrp = (nbp + 63) / 64;  // <= 65 (nb <= 4096)
-    if (tid < 64) {
-        uint32_t x = 0, carry = 0;
-        for (int g0 = 0; g0 < ngrp; g0 += 64) {  // at most two trips
-            const uint32_t v = g0 + tid < ngrp ? grp[g0 + tid] : 0u;
-            x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (tid >= d) x += y;
-            }
-            if (g0 + tid < ngrp) s_grp[g0 + tid] = carry + x - v;
-            carry += __shfl(x, 63, 64);
+        for (int u = 0; u < DSP_ROWS; u++) {
+            if (live && g0 + u < r1) pre[(size_t)(g0 + u) * nbp + b] = acc;
+            acc += v[u];
         }
     }
-    __syncthreads();
-    for (int b = tid; b < nbp; b += DS_THREADS) s_base[b] = s_grp[b >> 6] + loc[b];
-    __syncthreads();
+    if (wid == 0) {
+        if (live) tot[b] = total;
+        // the buckets the wave-per-bucket launch leaves to the next one (normally none), in any order
+        if (live && b != nbp - 1 && total > DS_WAVE_CAP) big[atomicAdd(nbig, 1u)] = (uint32_t)b;
+        const uint32_t x = wave_scan_incl(live ? total : 0u);
+        if (live) loc[b] = x - total;
+        if (lane == 63) grp[blockIdx.x] = x;
+    }
 }
 
+// The scattering pass.  First slot of every bucket for this workgroup in LDS (s_next[0 .. nbp]): the group sums scanned by
+// the first wave + the in-group prefix + the counting workgroups before this one.  As in the counting pass, everything a
+// thread reads is requested up front (keys, its share of the bucket words, the group sums).
+#define DS_MAX_NBP 4097  // ds_buckets() <= 4096, + the bucket of the Gaussians that touch no tile
 __global__ __launch_bounds__(DS_THREADS) void ds_scatter_kernel(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ krange, int P,
                                                                 int nb, const uint32_t* __restrict__ cnt,
                                                                 const uint32_t* __restrict__ loc,
                                                                 const uint32_t* __restrict__ grp,
                                                                 unsigned long long* __restrict__ tmp) {
-    extern __shared__ uint32_t s_mem[];  // (nb + 1) slots: next free slot of every bucket for this workgroup; 65 + 8 words
+    extern __shared__ uint32_t s_mem[];  // (nb + 1) slots: next free slot of every bucket for this workgroup; 65 words
     const int nbp = nb + 1;
     uint32_t* s_next = s_mem;
     uint32_t* s_grp = s_mem + nbp;
     const int tid = threadIdx.x;
-    uint32_t k[DS_ITEMS / DS_THREADS];
+    constexpr int NB_T = (DS_MAX_NBP + DS_THREADS - 1) / DS_THREADS;
+    uint32_t k[DS_ITEMS / DS_THREADS], first[NB_T];
 #pragma unroll
     for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
         k[u] = i < P ? keys[i] : 0u;
     }
+#pragma unroll
+    for (int u = 0; u < NB_T; u++) {
+        const int b = u * DS_THREADS + tid;
+        first[u] = b < nbp ? loc[b] + cnt[(size_t)blockIdx.x * nbp + b] : 0u;
+    }
+    const int ngrp = (nbp + 63) / 64;  // <= 65
+    if (tid < 64) {
+        uint32_t x = 0, carry = 0;
+        for (int g0 = 0; g0 < ngrp; g0 += 64) {  // at most two trips
+            const uint32_t v = g0 + tid < ngrp ? grp[g0 + tid] : 0u;
+            x = wave_scan_incl(v);
+            if (g0 + tid < ngrp) s_grp[g0 + tid] = carry + x - v;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        }
+    }
     const uint32_t kmin = krange[0];
-    const unsigned long long span = (unsigned long long)krange[1] | ((unsigned long long)krange[2] << 32);
-    ds_bucket_bases(loc, grp, nbp, s_grp, s_next);
-    for (int b = tid; b < nbp; b += DS_THREADS) s_next[b] += cnt[(size_t)blockIdx.x * nbp + b];  // + the workgroups before this one
+    const unsigned long long scale = (unsigned long long)krange[1] | ((unsigned long long)krange[2] << 32);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NB_T; u++) {
+        const int b = u * DS_THREADS + tid;
+        if (b < nbp) s_next[b] = s_grp[b >> 6] + first[u];
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < DS_ITEMS / DS_THREADS; u++) {
         const int i = blockIdx.x * DS_ITEMS + u * DS_THREADS + tid;
         if (i < P) {
-            const uint32_t pos = atomicAdd(&s_next[ds_bucket_of(k[u], kmin, span, nb)], 1u);
+            const uint32_t pos = atomicAdd(&s_next[ds_bucket_of(k[u], kmin, scale, nb)], 1u);
             tmp[pos] = ((unsigned long long)k[u] << 32) | (unsigned long long)(uint32_t)i;
         }
     }
@@ -260,30 +279,88 @@ struct ChunkAcc { uint32_t cur = 0xFFFFFFFFu, sum = 0u; };
 __device__ __forceinline__ void chunk_flush(const RankOut& ro, ChunkAcc& acc) {
     if (acc.cur != 0xFFFFFFFFu && acc.sum != 0u && (threadIdx.x & 63) == 0) atomicAdd(&ro.chunk_pairs[acc.cur], acc.sum);
 }
-__device__ __forceinline__ void rank_emit(const RankOut& ro, uint32_t r, bool valid, uint32_t id, bool keyed, ChunkAcc& acc) {
-    uint32_t tt = 0;
+struct RankRec { float4 c; uint32_t tt; };
+__device__ __forceinline__ RankRec rank_fetch(const RankOut& ro, bool valid, uint32_t id) {
+    RankRec q;
+    q.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    q.tt = 0u;
     if (valid) {
-        const float4 c = reinterpret_cast<const float4*>(ro.rec)[(size_t)id * 3 + 2];
-        tt = ro.tiles[id];
-        ro.sorted_idx[r] = id;
-        ro.ranklist[r] = make_uint4(id, __float_as_uint(c.z), __float_as_uint(c.w), tt);
+        q.c = reinterpret_cast<const float4*>(ro.rec)[(size_t)id * 3 + 2];
+        q.tt = ro.tiles[id];
     }
+    return q;
+}
+__device__ __forceinline__ void rank_store(const RankOut& ro, uint32_t r, uint32_t id, const RankRec& q) {
+    ro.sorted_idx[r] = id;
+    ro.ranklist[r] = make_uint4(id, __float_as_uint(q.c.z), __float_as_uint(q.c.w), q.tt);
+}
+__device__ __forceinline__ void rank_emit(const RankOut& ro, uint32_t r, bool valid, uint32_t id, bool keyed, ChunkAcc& acc) {
+    const RankRec q = rank_fetch(ro, valid, id);
+    const uint32_t tt = q.tt;
+    if (valid) rank_store(ro, r, id, q);
     if (!keyed) return;  // the Gaussians that touch no tile: nothing to add
     const uint32_t cA = (uint32_t)__builtin_amdgcn_readfirstlane((int)r) >> 8;  // (lane 0 holds the trip's first rank)
     uint32_t sA = (valid && (r >> 8) == cA) ? tt : 0u, sB = (valid && (r >> 8) != cA) ? tt : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        sA += __shfl_xor(sA, d, 64);
-        sB += __shfl_xor(sB, d, 64);
-    }
+    sA = wave_sum(sA);
+    sB = wave_sum(sB);
     if (acc.cur != cA) { chunk_flush(ro, acc); acc.cur = cA; acc.sum = 0u; }
     acc.sum += sA;
     if (sB != 0u) { chunk_flush(ro, acc); acc.cur = cA + 1u; acc.sum = sB; }
 }
 
+// A bucket of up to 64 EPL composites without a sorting network: the composites are distinct, so an element's place is the
+// number of smaller ones, counted against broadcast LDS reads (n reads and n EPL compares per lane; the network is
+// ~log^2 n dependent LDS round trips of ~80 instructions each, 9 of this kernel's 13 us at ~64 per bucket).  The owner lane
+// writes the element's rank record straight to its place; what it needs of the Gaussian is requested before the counting
+// starts.  At most 256 composites: they span at most two chunks of 256 ranks.
+template <int EPL>
+__device__ __forceinline__ void ds_small_bucket(const unsigned long long* __restrict__ seg, unsigned long long* s, int n,
+                                                uint32_t start, const RankOut& ro) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long a[EPL];
+    RankRec q[EPL];
+    uint32_t rk[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) a[e] = e * 64 + lane < n ? seg[e * 64 + lane] : ~0ull;
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        if (e * 64 + lane < n) s[e * 64 + lane] = a[e];
+        q[e] = rank_fetch(ro, e * 64 + lane < n, (uint32_t)a[e]);
+        rk[e] = 0u;
+    }
+    if (lane < 8) s[n + lane] = ~0ull;  // the reads below come in eights: the slack counts for nothing
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        unsigned long long v[8];  // (the same words for every lane: broadcasts, all eight in flight)
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = s[j0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) rk[e] += v[u] < a[e] ? 1u : 0u;
+        }
+    }
+    const uint32_t cA = start >> 8;
+    uint32_t sA = 0u, sB = 0u;
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        if (e * 64 + lane < n) {
+            const uint32_t r = start + rk[e];
+            rank_store(ro, r, (uint32_t)a[e], q[e]);
+            if ((r >> 8) == cA) sA += q[e].tt; else sB += q[e].tt;
+        }
+    }
+    sA = wave_sum(sA);
+    sB = wave_sum(sB);
+    if (lane == 0) {
+        if (sA) atomicAdd(&ro.chunk_pairs[cA], sA);
+        if (sB) atomicAdd(&ro.chunk_pairs[cA + 1u], sB);
+    }
+}
+
 // One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~64
 // per bucket): the network runs in LDS without workgroup barriers -- a wave's LDS operations execute in order.
-#define DS_WAVE_CAP 1024
 __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned long long* __restrict__ tmp,
                                                                  const uint32_t* __restrict__ tot,
                                                                  const uint32_t* __restrict__ loc,
@@ -293,13 +370,12 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
     const int lane = threadIdx.x;
     // bucket; bucket nb holds the Gaussians that touch no tile and is shared by the workgroups nb, nb + 1, ...
     const int b = min((int)blockIdx.x, nb);
+    // (all three requested before the first is looked at; nb <= 4096: at most 64 groups before a bucket's own)
     const int n = (int)tot[b];
+    const uint32_t in_group = loc[b];
+    uint32_t part = lane < (b >> 6) ? grp[lane] : 0u;
     if (n == 0 || (n > DS_WAVE_CAP && b != nb)) return;  // (larger buckets: ds_bucket_sort_kernel)
-    uint32_t part = 0;
-    for (int q = lane; q < (b >> 6); q += 64) part += grp[q];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    const uint32_t start = part + loc[b];
+    const uint32_t start = wave_sum(part) + in_group;
     const unsigned long long* seg = tmp + start;
     ChunkAcc acc;
     if (b == nb) {
@@ -310,6 +386,9 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
         }
         return;
     }
+    if (n <= 64) { ds_small_bucket<1>(seg, s, n, start, ro); return; }  // (wave-uniform)
+    if (n <= 128) { ds_small_bucket<2>(seg, s, n, start, ro); return; }
+    if (n <= 256) { ds_small_bucket<4>(seg, s, n, start, ro); return; }
     // between two steps: nothing may be kept in registers or moved across (the LDS itself keeps a wave's accesses in order)
     auto step_done = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -320,9 +399,9 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
     const int half = n_pad >> 1;
-    for (int k = 2; k <= n_pad; k <<= 1) {
+    for (int k = 2, lk = 0; k <= n_pad; k <<= 1, lk++) {  // lk = log2(k / 2)
         for (int t = lane; t < half; t += 64) {  // flip step (see ds_bitonic)
-            const int blk = t / (k >> 1), off = t % (k >> 1);
+            const int blk = t >> lk, off = t & ((k >> 1) - 1);
             const int i = blk * k + off, p = blk * k + (k - 1 - off);
             if (p < n) {
                 const unsigned long long a = s[i], c = s[p];
@@ -348,69 +427,73 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
     chunk_flush(ro, acc);
 }
 
-// One workgroup per bucket.  Buckets of [n_lo, n_hi] composites are handled by this launch (the others by the launch of
-// the other LDS size); at most CAP of them are sorted in LDS, more in global memory.
+// The buckets of more than DS_WAVE_CAP composites (the list the prefix pass made; normally empty, and the few workgroups of
+// this launch leave at once).  One workgroup per bucket and trip: up to CAP composites are sorted in LDS, more in global memory.
 template <int CAP>
 __global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned long long* __restrict__ tmp,
                                                                     const uint32_t* __restrict__ tot,
                                                                     const uint32_t* __restrict__ loc,
-                                                                    const uint32_t* __restrict__ grp, int nb, int n_lo,
-                                                                    const RankOut ro) {
+                                                                    const uint32_t* __restrict__ grp,
+                                                                    const uint32_t* __restrict__ nbig,
+                                                                    const uint32_t* __restrict__ big, const RankOut ro) {
     __shared__ unsigned long long s[CAP];
     __shared__ uint32_t s_grp[4];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;  // bucket; bucket nb holds the Gaussians that touch no tile
-    const int n = (int)tot[b];
-    if (n < n_lo || b == nb) return;  // (workgroup-uniform) not this launch's bucket
-    // first slot of this bucket: the groups before its own + its prefix inside the group
-    {
-        const int g = b >> 6;
-        uint32_t part = 0;
-        for (int q = tid; q < g; q += DS_THREADS) part += grp[q];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-        if ((tid & 63) == 0) s_grp[tid >> 6] = part;
-        __syncthreads();
-    }
-    const uint32_t start = s_grp[0] + s_grp[1] + s_grp[2] + s_grp[3] + loc[b];
-    unsigned long long* seg = tmp + start;
-    ChunkAcc acc;
-    if (n <= CAP) {
-        for (int i = tid; i < n; i += DS_THREADS) s[i] = seg[i];
-        __syncthreads();
-        ds_bitonic(n, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
-                   [&]() { __syncthreads(); });
+    const int count = (int)*nbig;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {  // (workgroup-uniform)
+        const int b = (int)big[j];
+        const int n = (int)tot[b];
+        // first slot of this bucket: the groups before its own + its prefix inside the group
+        {
+            const int g = b >> 6;
+            uint32_t part = 0;
+            for (int q = tid; q < g; q += DS_THREADS) part += grp[q];
+            part = wave_sum(part);
+            __syncthreads();  // (the trip before has read s_grp and s)
+            if ((tid & 63) == 0) s_grp[tid >> 6] = part;
+            __syncthreads();
+        }
+        const uint32_t start = s_grp[0] + s_grp[1] + s_grp[2] + s_grp[3] + loc[b];
+        unsigned long long* seg = tmp + start;
+        ChunkAcc acc;
+        if (n <= CAP) {
+            for (int i = tid; i < n; i += DS_THREADS) s[i] = seg[i];
+            __syncthreads();
+            ds_bitonic(n, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
+                       [&]() { __syncthreads(); });
+            for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
+                const int i = i0 + tid;
+                rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
+            }
+            chunk_flush(ro, acc);
+            continue;
+        }
+        // A bucket larger than the LDS takes (most of the scene at one depth): the same network in global memory, by this
+        // workgroup alone.  The elements go through agent-scope (L2) accesses and every stage ends with a device fence, so
+        // that a wave reads what another wave of the workgroup stored in the stage before.  Slow, exact.
+        ds_bitonic(n,
+                   [&](long long i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                   [&](long long i, unsigned long long v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                   [&]() { __threadfence(); __syncthreads(); });
         for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
             const int i = i0 + tid;
-            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
+            rank_emit(ro, start + i, i < n,
+                      i < n ? (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, true, acc);
         }
         chunk_flush(ro, acc);
-        return;
     }
-    // A bucket larger than the LDS takes (most of the scene at one depth): the same network in global memory, by this
-    // workgroup alone.  The elements go through agent-scope (L2) accesses and every stage ends with a device fence, so
-    // that a wave reads what another wave of the workgroup stored in the stage before.  Slow, exact.
-    ds_bitonic(n,
-               [&](long long i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-               [&](long long i, unsigned long long v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-               [&]() { __threadfence(); __syncthreads(); });
-    for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
-        const int i = i0 + tid;
-        rank_emit(ro, start + i, i < n,
-                  i < n ? (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, true, acc);
-    }
-    chunk_flush(ro, acc);
 }
 
 int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uint32_t* wave_kmax, int nwaves, int P,
                       DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s) {
     const int nbp = st.nb + 1;
-    const size_t lds_count = (size_t)(nbp + 8) * 4, lds_scatter = (size_t)(nbp + 66) * 4;
+    if (nbp > DS_MAX_NBP) return GS_E_BAD_ARG;  // (ds_buckets() never asks for more)
+    const size_t lds_count = (size_t)nbp * 4, lds_scatter = (size_t)(nbp + 66) * 4;
     hipLaunchKernelGGL(ds_count_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_count, s, keys, wave_kmin, wave_kmax, nwaves, P,
                        st.nb, st.cnt, st.range, pn);
     GS_LAUNCH_CHECK("depth_sort.count", debug, s);
-    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(64), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp, nbp,
-                       st.blocks);
+    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(256), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp,
+                       st.range + 3, st.big, nbp, st.blocks);
     GS_LAUNCH_CHECK("depth_sort.prefix", debug, s);
     hipLaunchKernelGGL(ds_scatter_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_scatter, s, keys, st.range, P, st.nb, st.pre,
                        st.loc, st.grp, st.tmp);
@@ -420,8 +503,9 @@ int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uin
     const int helpers = P / 1024 < 1 ? 1 : (P / 1024 > 512 ? 512 : P / 1024);  // waves sharing the no-tile bucket
     hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(st.nb + helpers), dim3(64), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, ro);
     GS_LAUNCH_CHECK("depth_sort.buckets", debug, s);
-    hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP_BIG>, dim3(nbp), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp,
-                       st.nb, DS_WAVE_CAP + 1, ro);
+    const int big_wgs = nbp < 64 ? nbp : 64;
+    hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP_BIG>, dim3(big_wgs), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp,
+                       st.range + 3, st.big, ro);
     GS_LAUNCH_CHECK("depth_sort.big_buckets", debug, s);
     return GS_OK;
 }
