@@ -77,8 +77,4 @@ __device__ __forceinline__ float dpp_get(float v) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_max(v); }  // (common.h: DPP ladder)

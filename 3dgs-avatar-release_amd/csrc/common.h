@@ -248,6 +248,14 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t x) { return ~wave_max(~x); }
+// (float: the sum is taken in the ladder's fixed order -- the same bits on every run)
+__device__ __forceinline__ float wave_sum(float x) {
+#define GS_FSUM_STEP(CTRL, MASK) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, MASK, 0xF, false));
+    GS_FSUM_STEP(0x111, 0xF) GS_FSUM_STEP(0x112, 0xF) GS_FSUM_STEP(0x114, 0xF) GS_FSUM_STEP(0x118, 0xF)
+    GS_FSUM_STEP(0x142, 0xA) GS_FSUM_STEP(0x143, 0xC)
+#undef GS_FSUM_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
 
 __device__ __forceinline__ void zero_job(const ZeroJob z) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;

@@ -72,13 +72,15 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
     }
     // fold the eight row slots (lane ^ 2, lane ^ 4, lane ^ 8): lanes with h = 0 end up with the sums 0..3 and 8, lanes
     // with h = 1 with the sums 4..7
+    // (DPP: the other pair of the quad, then the quads 4 and 8 lanes down the row of 16 -- every lane ends up with the
+    // sum over the eight lanes of its parity; three VALU instructions per sum instead of three trips through the LDS unit)
     float f[5] = {a0, a1, a2, a3, a8};
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         float v = f[c];
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm:[2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
         f[c] = v;
     }
     // The rows hold raw sums over pixels: (t dx, t dy, t dx^2, t dx dy, t dy^2, G dL/dalpha, w g_rgb) with

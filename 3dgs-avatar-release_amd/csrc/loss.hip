@@ -34,8 +34,7 @@ __global__ __launch_bounds__(L1_THREADS) void l1_partial_kernel(const float* __r
         acc += fabsf(d);
         grad[i] = sgn_over_n(d, inv_n);
     }
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    acc = wave_sum(acc);
     if (lane == 0) ws[wid] = acc;
     __syncthreads();
     if (tid == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
@@ -47,8 +46,7 @@ __global__ __launch_bounds__(L1_THREADS) void l1_final_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float acc = 0.f;
     for (int i = tid; i < nparts; i += L1_THREADS) acc += partial[i];
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    acc = wave_sum(acc);
     if (lane == 0) ws[wid] = acc;
     __syncthreads();
     if (tid == 0) loss[0] = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_n;
@@ -71,8 +69,7 @@ __global__ __launch_bounds__(L1_THREADS) void bce_partial_kernel(const float* __
         const bool inside = xv >= 1.0e-3f && xv <= 1.0f - 1.0e-3f;  // clamp passes the gradient on its closed range
         grad[i] = inside ? (p - t) / (p * (1.0f - p)) * inv_n : 0.f;
     }
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    acc = wave_sum(acc);
     if (lane == 0) ws[wid] = acc;
     __syncthreads();
     if (tid == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
@@ -229,8 +226,7 @@ __global__ __launch_bounds__(SS_NT) void ssim_fwd_kernel(int H, int W, const flo
             }
         }
     }
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) val += __shfl_xor(val, k, 64);
+    val = wave_sum(val);
     if ((tid & 63) == 0) ws[tid >> 6] = val;
     __syncthreads();
     if (tid == 0) partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
@@ -242,8 +238,7 @@ __global__ __launch_bounds__(256) void ssim_final_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float acc = 0.f;
     for (int i = tid; i < nparts; i += 256) acc += partial[i];
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    acc = wave_sum(acc);
     if (lane == 0) ws[wid] = acc;
     __syncthreads();
     if (tid == 0) out[0] = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_n;

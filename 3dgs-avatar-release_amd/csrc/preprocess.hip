@@ -147,12 +147,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     uint32_t wsum = live ? tt : 0u;
     const bool keyed = live && tt != 0u;
     uint32_t kmin = keyed ? __float_as_uint(depth) : 0xFFFFFFFFu, kmax = keyed ? __float_as_uint(depth) : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        wsum += __shfl_xor(wsum, d, 64);
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
-    }
+    wsum = wave_sum(wsum);
+    kmin = wave_min(kmin);
+    kmax = wave_max(kmax);
     if ((threadIdx.x & 63) == 0) {
         wave_tiles[gi >> 6] = wsum;
         wave_kmin[gi >> 6] = kmin;

@@ -30,9 +30,12 @@ __device__ __forceinline__ float stage_cost(float a, float b) {
 }
 
 template <int PIX>
-__global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec, float* __restrict__ out, int entries, int nrec) {
+__global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec, float* __restrict__ out, int entries, int nrec,
+                                                 unsigned long long* clk) {
     __shared__ float4 srec[66 * 3];
     const int lane = threadIdx.x;
+    // shader clock under this load: s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz)
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     const float pxf = (float)(blockIdx.x % 128 * 8 + (lane & 7)), pyf = (float)(blockIdx.x / 128 * 8 * PIX + (lane >> 3));
     uint32_t vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -128,6 +131,11 @@ __global__ __launch_bounds__(64) void fwd_kernel(const float4* __restrict__ rec,
 #pragma unroll
     for (int p = 0; p < PIX; p++)
         out[((size_t)blockIdx.x * PIX + p) * 64 + lane] = C0[p] + C1[p] + C2[p] + T[p] + __uint_as_float(mark[p] & 1u);
+    if (clk && lane == 0 && (blockIdx.x & 63) == 0) {
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&clk[0], t1 - t0);
+        atomicAdd(&clk[1], r1 - r0);
+    }
 }
 
 // Mode 2: the staged entry is not written to LDS at all: it stays in the staging lane's registers and entry j is
@@ -191,13 +199,16 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
+    unsigned long long* clk;
+    CHECK(hipMalloc(&clk, 16));
     for (int mode = 0; mode < 3; mode++) {
+        CHECK(hipMemset(clk, 0, 16));
         const int waves = mode == 1 ? quads / 2 : quads, ent = mode == 1 ? (int)(E * uni + 0.5f) : E;
         float best = 1e9f;
         for (int it = 0; it < 40; it++) {
             CHECK(hipEventRecord(e0));
-            if (mode == 1) hipLaunchKernelGGL(fwd_kernel<2>, dim3(waves), dim3(64), 0, 0, rec, out, ent, nrec);
-            else if (mode == 0) hipLaunchKernelGGL(fwd_kernel<1>, dim3(waves), dim3(64), 0, 0, rec, out, ent, nrec);
+            if (mode == 1) hipLaunchKernelGGL(fwd_kernel<2>, dim3(waves), dim3(64), 0, 0, rec, out, ent, nrec, clk);
+            else if (mode == 0) hipLaunchKernelGGL(fwd_kernel<1>, dim3(waves), dim3(64), 0, 0, rec, out, ent, nrec, clk);
             else hipLaunchKernelGGL(fwd_readlane_kernel, dim3(waves), dim3(64), 0, 0, rec, out, ent, nrec);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
@@ -207,6 +218,9 @@ int main(int argc, char** argv) {
         }
         printf("%s: %5d waves x %3d entries: %.1f us\n", mode == 0 ? "1 pixel per lane, LDS-staged entries (shipped loop)" :
                (mode == 1 ? "2 pixels per lane, LDS-staged entries" : "1 pixel per lane, entries by v_readlane"), waves, ent, best * 1e3f);
+        unsigned long long hc[2];
+        CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+        if (hc[1]) printf("    shader clock while it runs: %.2f GHz (s_memtime / s_memrealtime over the waves' lifetimes)\n", (double)hc[0] / (double)hc[1] * 0.1);
     }
     return 0;
 }

@@ -3,7 +3,9 @@
 #include <stdio.h>
 #include <vector>
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed, unsigned long long* clk = nullptr) {
+    // shader clock under this load: s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz), first wave of a block
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     float a[8];
     for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x * 1e-3f;
     const float m = 1.0001f, c = 0.5f;
@@ -34,6 +36,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     float s = 0;
     for (int i = 0; i < 8; i++) s += a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (clk && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&clk[0], t1 - t0);
+        atomicAdd(&clk[1], r1 - r0);
+    }
 }
 template <int MODE>
 void run(const char* name, int blocks_per_cu) {
@@ -44,13 +51,16 @@ void run(const char* name, int blocks_per_cu) {
     hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(256), 0, 0, d, 16, 1.0f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(256), 0, 0, d, iters, 1.0f);
+    unsigned long long* clk; hipMalloc(&clk, 16); hipMemset(clk, 0, 16);
+    hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(256), 0, 0, d, iters, 1.0f, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
+    unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost); hipFree(clk);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double winstr = (double)nb * 4 /*waves*/ * iters * 32.0;  // wave-instructions of the measured op
     double per_simd = winstr / 1024.0;
-    printf("%-8s blocks/CU=%d  %.3f ms  wave-instr/SIMD=%.3g  ns/instr/SIMD=%.3f  (cycles @2.4GHz: %.2f)\n", name, blocks_per_cu, ms,
-           per_simd, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+    const double ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+    printf("%-8s blocks/CU=%d  %.3f ms  wave-instr/SIMD=%.3g  ns/instr/SIMD=%.3f  (cycles @2.4GHz: %.2f)  shader clock %.2f GHz -> %.2f cycles\n", name, blocks_per_cu, ms,
+           per_simd, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4, ghz, ms * 1e6 / per_simd * ghz);
     hipFree(d);
 }
 int main() {
