@@ -385,6 +385,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
                                                           uint32_t* __restrict__ order, const PairCount pc,
                                                           const FillJob fill, const LongLists ll) {
     if (blockIdx.x > 0) {  // the side job; workgroup 0 does the ordering
+        if (fill.clean && *fill.clean == MARKS_CLEAN) return;  // (workgroup-uniform) the forward has done it
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         for (size_t k = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; k < fill.quads; k += (size_t)(gridDim.x - 1) * 1024)
             if (fill.stream) store_stream(&fill.ptr[k], ones); else fill.ptr[k] = ones;
@@ -624,9 +625,10 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
 
 int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, int ntiles, uint32_t* order, PairCount pc,
                       FillJob fill, LongLists ll, int debug, hipStream_t s) {
-    // enough side workgroups to fill at HBM rate, no more than the job has 16 KB pieces
+    // side workgroups: enough to fill at HBM rate (4 MB in flight per sweep), no more than the job has 16 KB pieces -- and
+    // few enough to cost nothing when they find the job done (FillJob::clean) and leave
     const size_t pieces = (fill.quads + 1023) / 1024;
-    const int side = fill.ptr ? (int)(pieces < 1024 ? pieces : 1024) : 0;
+    const int side = fill.ptr ? (int)(pieces < 255 ? pieces : 255) : 0;
     if (ntiles <= 32 * 1024)
         hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1 + side), dim3(1024), 0, s, reinterpret_cast<const uint2*>(ranges),
                            keys, mode, ntiles, order, pc, fill, ll);

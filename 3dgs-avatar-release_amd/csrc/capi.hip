@@ -25,6 +25,7 @@ static void tune_defaults() {
     g_tune[GS_TUNE_ONES_FAST].store(1);
     g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
     g_tune[GS_TUNE_BWD_ORDER].store(1);
+    g_tune[GS_TUNE_FWD_MARKS].store(1);
 }
 int gs_tune_get(int key) {
     tune_defaults();
@@ -240,6 +241,11 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
+    if (cap > 0) {  // the backward's row marks, set on the side by the render launch (BinLayout::marks) -- or declared unset
+        ql.marks = gs_tune_get(GS_TUNE_FWD_MARKS) ? (uint4*)(b + B.marks) : nullptr;
+        ql.mark_quads = (size_t)cap;
+        ql.marks_flag = (uint32_t*)(b + B.marks_flag);
+    }
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -420,13 +426,15 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
         ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
         ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
-        uint32_t* q8 = (uint32_t*)((char*)scratch + scratch_rows_bytes(D));
-        uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(a->P));
-        // ROW_UNWRITTEN in every word of q8 (D * 16 bytes), written by the tile-order launch's other workgroups
+        // the row marks: in the binning state, where the forward has set every word to ROW_UNWRITTEN beside its render
+        // kernel; if a backward has run on this state since (marks_flag), the tile-order launch's other workgroups do it
+        uint32_t* q8 = (uint32_t*)(const_cast<char*>(b) + B.marks);
+        uint32_t* marks_flag = (uint32_t*)(const_cast<char*>(b) + B.marks_flag);
+        uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_sums_bytes(a->P));
         const bool own_order = gs_tune_get(GS_TUNE_BWD_ORDER) != 0;
         { StageScope sc_("tile_order", s);
         rc = launch_tile_order((const uint32_t*)(im + I.ranges), ql.qcount, own_order ? 1 : -1, I.gx * I.gy, order_b, PairCount{nullptr, 0},
-                               FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1},
+                               FillJob{reinterpret_cast<uint4*>(q8), (size_t)D, gs_tune_get(GS_TUNE_NT_STORES) & 1, marks_flag},
                                LongLists{0, nullptr}, a->debug, s); }
         if (rc != GS_OK) return rc;
         if (!own_order) order_b = (uint32_t*)(const_cast<char*>(im) + I.order);
@@ -451,9 +459,9 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
     }
     StageScope sc_("gaussian_bwd", s);
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
-                                    (const uint32_t*)(g + L.clamped), (const uint32_t*)((const char*)scratch + scratch_rows_bytes(D)),
-                                    (const float*)scratch,
-                                    (float*)((char*)scratch + scratch_rows_bytes(D) + scratch_valid_bytes(D)), *gr, s);
+                                    (const uint32_t*)(g + L.clamped), D > 0 ? (const uint32_t*)(b + B.marks) : nullptr,
+                                    (const float*)scratch, (float*)((char*)scratch + scratch_rows_bytes(D)),
+                                    D > 0 ? (uint32_t*)(const_cast<char*>(b) + B.marks_flag) : nullptr, *gr, s);
 }
 
 int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
@@ -700,6 +708,7 @@ int gs_tuning(const char* name, int value) {
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
+    if (strcmp(name, "fwd_marks") == 0) { g_tune[GS_TUNE_FWD_MARKS].store(value); return GS_OK; }  // 0: the backward sets its row marks itself (A/B)
     if (strcmp(name, "bwd_order") == 0) { g_tune[GS_TUNE_BWD_ORDER].store(value); return GS_OK; }  // 0: the backward walks the tiles in the forward's launch order (A/B: + 12 us at config 3)
     if (strcmp(name, "depth_sort") == 0) { g_tune[GS_TUNE_DEPTH_SORT].store(value); return GS_OK; }  // 1 bucket sort, 0 LSD radix
     return GS_E_BAD_ARG;

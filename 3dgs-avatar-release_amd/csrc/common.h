@@ -81,7 +81,7 @@ static inline GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t point_list, qlist, total;
+    size_t point_list, qlist, marks, marks_flag, total;
 };
 static inline BinLayout bin_layout(int64_t D) {
     BinLayout L;
@@ -90,6 +90,11 @@ static inline BinLayout bin_layout(int64_t D) {
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     L.point_list = take(n * 4);  // Gaussian indices, tile-major, (depth, index) order inside a tile
     L.qlist = take(n * 16);      // per quadrant: compacted Gaussian indices the forward visited
+    // The backward's gradient-row marks (one word per row, four rows per pair; render_bwd.hip): ROW_UNWRITTEN in every word
+    // is what the backward starts from.  They live HERE, not in the backward's scratch, so that the forward can write them
+    // in the shadow of its VALU-bound render kernel; marks_flag says whether they still are as the forward left them.
+    L.marks = take(n * 16);
+    L.marks_flag = take(4);
     L.total = o;
     return L;
 }
@@ -124,7 +129,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 // process-wide tuning switches (gs_tuning)
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_BWD_ORDER = 8, GS_TUNE_COUNT = 9 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_BWD_ORDER = 8, GS_TUNE_FWD_MARKS = 9, GS_TUNE_COUNT = 10 };
 int gs_tune_get(int key);
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
@@ -384,7 +389,8 @@ int launch_ssim_backward(int C, int H, int W, const float* img1, const float* im
 
 // `fill`: 16-byte words the kernel's other workgroups set to all-ones while the first one orders the tiles (the
 // backward's ROW_UNWRITTEN marks: a fill launch less, and it overlaps the single-workgroup ordering)
-struct FillJob { uint4* ptr; size_t quads; int stream = 0; };
+#define MARKS_CLEAN 0x600DF111u  // BinLayout::marks_flag: every mark is ROW_UNWRITTEN (the forward's fill, no backward since)
+struct FillJob { uint4* ptr; size_t quads; int stream = 0; const uint32_t* clean = nullptr; /* skip the job if *clean == MARKS_CLEAN */ };
 
 // 16-byte store that does not stay in the L2 as a dirty line (streamed output nothing re-reads soon)
 typedef uint32_t gs_u32x4 __attribute__((ext_vector_type(4)));
@@ -409,6 +415,10 @@ struct QuadLists {
     float4* ckpt = nullptr;  // compositing state at the chunk boundaries (see BWD_CH), or null
     uint32_t* ck_start = nullptr;  // [quadrant][chunks]: compacted index every chunk starts at
     int chunks = 1;          // chunks per quadrant the backward runs (1: one wave per quadrant walks the whole list)
+    // forward: the backward's row marks, filled on the side (null: not this render's job), and their state word
+    uint4* marks = nullptr;
+    size_t mark_quads = 0;
+    uint32_t* marks_flag = nullptr;
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
@@ -435,10 +445,10 @@ int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
-                             const GsGrads& g, hipStream_t s);
+                             uint32_t* marks_flag, const GsGrads& g, hipStream_t s);
 // backward scratch: [4 D rows x 32 B: sums 0..7 of (pair, quadrant) at index gradient_row(...) (below), pairs in
-// emission order (one 32-byte sector per row) | 4 D words: sum 8 of the row, or ROW_UNWRITTEN (the caller
-// fills the array with 0xFF bytes) | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)]
+// emission order (one 32-byte sector per row) | P rows x 48 B of per-Gaussian sums | launch order (u32 per tile)];
+// sum 8 of every row, or ROW_UNWRITTEN: the 4 D mark words of the binning state (BinLayout::marks)
 #define ROW_UNWRITTEN 0xFFFFFFFFu  // a NaN pattern no arithmetic produces
 // Row of (pair, quadrant): Gaussian i owns the 4 tt rows [4 first_pair, 4 (first_pair + tt)), tt = w h tiles of its
 // rectangle, i.e. a grid of 2w x 2h quadrants.  The rows are laid out ROW-MAJOR OVER THAT QUADRANT GRID: row = 4 first_pair
@@ -451,10 +461,9 @@ __host__ __device__ __forceinline__ uint32_t gradient_row(uint32_t first_pair, u
     return first_pair * 4u + (2u * ty + (q >> 1)) * (2u * w) + 2u * tx + (q & 1u);
 }
 static inline size_t scratch_rows_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 32, 256); }
-static inline size_t scratch_valid_bytes(int64_t D) { return align_up((size_t)(D > 0 ? D : 1) * 4 * 4, 256); }
 static inline size_t scratch_sums_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * REC_F * 4, 256); }
 static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {
-    return scratch_rows_bytes(D) + scratch_valid_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);
+    return scratch_rows_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);  // (the row marks: BinLayout)
 }
 
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);

@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(int P, const int32_
                                                              const uint32_t* __restrict__ tiles,
                                                              const uint32_t* __restrict__ q8,
                                                              const float4* __restrict__ qrows,
-                                                             float4* __restrict__ sums) {
+                                                             float4* __restrict__ sums, uint32_t* __restrict__ marks_flag) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && marks_flag) *marks_flag = 0u;  // the marks are no longer as the forward left them (common.h: MARKS_CLEAN)
     const int i = t >> 4, j = t & 15;
     const int rs = j >> 1, h = j & 1;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a8 = 0.f;
@@ -337,11 +338,11 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
                              const uint32_t* clamped, const uint32_t* q8, const float* qrows, float* sums,
-                             const GsGrads& g, hipStream_t s) {
+                             uint32_t* marks_flag, const GsGrads& g, hipStream_t s) {
     const float fy = a.H / (2.0f * a.tanfovy), fx = a.W / (2.0f * a.tanfovx);
     hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)(((size_t)a.P * 16 + 255) / 256)), dim3(256), 0, s, a.P, radii,
                        reinterpret_cast<const float4*>(rec), tiles, q8,
-                       reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums));
+                       reinterpret_cast<const float4*>(qrows), reinterpret_cast<float4*>(sums), marks_flag);
     GS_LAUNCH_CHECK("segment_reduce", a.debug, s);
     const size_t lds = a.shs ? (size_t)GB_THREADS * ((3 * a.M) | 1) * sizeof(float) : 0;
     hipLaunchKernelGGL(gaussian_bwd_kernel, dim3((a.P + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), lds, s, a.P, a.sh_degree, a.M, a.means3D,

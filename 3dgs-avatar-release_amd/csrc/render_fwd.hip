@@ -40,7 +40,22 @@ struct FwdArgs {
     // ... and, if not null, a word that is ZERO when that second render's colours are all (1, 1, 1): the render then
     // leaves at once -- second_ones_kernel writes the image, 1 - T, from the first render's state
     const unsigned long long* __restrict__ not_ones;
+    // the side job of this launch (null: none): ROW_UNWRITTEN into every mark word of the backward's gradient rows
+    // (BinLayout::marks) -- this kernel is bound by its VALU stream, the stores ride along; *marks_flag := MARKS_CLEAN
+    uint4* __restrict__ marks;
+    size_t mark_quads;
+    uint32_t* __restrict__ marks_flag;
 };
+__device__ __forceinline__ void forward_side_fill(const FwdArgs& A) {
+    if (!A.marks) {  // not this launch's job; a state word it owns must not keep what an earlier use of the memory left there
+        if (A.marks_flag && blockIdx.x == 0 && threadIdx.x == 0) *A.marks_flag = 0u;
+        return;
+    }
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.mark_quads; k += (size_t)gridDim.x * blockDim.x)
+        store_stream(&A.marks[k], ones);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *A.marks_flag = MARKS_CLEAN;  // (read by a later launch: the backward's)
+}
 
 // between two phases of ONE wave that exchange data through LDS (a wave's LDS operations execute in order)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -256,9 +271,11 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
     __shared__ float4 srec[66 * 3];
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
-    if (slot >= A.ntiles) return;
-    if (FQ && A.not_ones && *A.not_ones == 0ull) return;
-    render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
+    if (slot < A.ntiles && !(FQ && A.not_ones && *A.not_ones == 0ull))
+        render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
+    // The side job BEHIND the wave's own work (same-box A/B, config 3, whole step: no side job 617.3 us; here 611.5 us;
+    // between the wave's first gathers and its loop 624.9 us -- the stores queue in front of every wave's second batch)
+    forward_side_fill(A);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -526,14 +543,15 @@ __global__ __launch_bounds__(FWD4_BATCH) void render_fwd_small_kernel(const FwdA
     __shared__ uint32_t s_cnt[4], s_flag[4], s_lastk[4];
     int slot, q;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
-    if (slot >= A.ntiles) return;
-    if (FQ && A.not_ones && *A.not_ones == 0ull) return;
-    const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
-    if (ov >> 31) {
-        render_quadrant_4<FQ>(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
-    } else if (threadIdx.x < 64) {
-        render_quadrant_1<FQ>(A, (int)ov, q, srec);  // (no workgroup barrier inside: the other waves have left)
+    if (slot < A.ntiles && !(FQ && A.not_ones && *A.not_ones == 0ull)) {
+        const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
+        if (ov >> 31) {
+            render_quadrant_4<FQ>(A, (int)(ov & 0x7FFFFFFFu), q, srec, s_cnt, s_flag, s_lastk);
+        } else if (threadIdx.x < 64) {
+            render_quadrant_1<FQ>(A, (int)ov, q, srec);  // (no workgroup barrier inside: the other waves do the side job)
+        }
     }
+    forward_side_fill(A);
 }
 
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
@@ -543,7 +561,7 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
-                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones};
+                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag};
     const dim3 grid(render_grid_blocks(gx * gy, xmap));
     const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where

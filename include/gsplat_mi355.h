@@ -149,7 +149,11 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
 /* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
  * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `num_rendered` is the number of
  * pairs the forward's binning state was carved for (the capacity given to gs_forward, or the count given to
- * gs_forward_render).  `scratch` holds gs_backward_scratch_bytes(num_rendered, P, W, H) bytes. */
+ * gs_forward_render).  `scratch` holds gs_backward_scratch_bytes(num_rendered, P, W, H) bytes.
+ * The binning state also holds the mark word of every gradient row the backward writes (all "unwritten" on entry): the
+ * forward's render launch sets them on the side and says so in a state word; a backward that finds them used by an
+ * earlier backward of the same forward sets them itself.  A backward therefore WRITES that part of `binning`
+ * (the pointer is const for the lists and ranges it reads); two backwards of one forward must not run concurrently. */
 int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t num_rendered,
                 const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,
@@ -307,7 +311,9 @@ int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches
 
 /* process-wide tuning switches for experiments and A/B measurements.  Without effect on the results: "xcd_map" (1: the
  * four quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's
- * row-mark fill is written with streaming stores).  With an effect of fp32 rounding (which kernels render a frame of few,
+ * row-mark fill is written with streaming stores), "fwd_marks" (1: the forward's render launch sets the backward's row
+ * marks on the side, 0: every backward sets them itself), "bwd_order" (1: the backward orders the tiles by the forward's
+ * per-quadrant last contributors, 0: walks them in the forward's launch order).  With an effect of fp32 rounding (which kernels render a frame of few,
  * long tile lists; flip them between frames only, "small_tiles" also changes the image state's size): "fwd4" (1: four
  * waves per quadrant, four entries per step on the marked tiles), "bwd_chunks" (1: backward in chunks from the forward's
  * checkpoints), "small_tiles" (images of up to this many tiles use both whatever GsFwdArgs.long_lists says; 2048).  "shared_qlist"

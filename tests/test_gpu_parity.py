@@ -1871,3 +1871,47 @@ def test_two_host_threads_on_two_streams_render_the_single_stream_bits():
     for i in range(len(cams)):
         for a, b in zip(got[i], want[i]):
             assert torch.equal(a, b), i
+
+
+@pytest.mark.gpu
+def test_gradient_row_marks_set_by_the_forward_and_by_a_repeated_backward():
+    """The backward starts from ROW_UNWRITTEN in every mark word of its gradient rows.  The forward's render launch sets
+    them on the side (binning state; a state word says they are untouched), a backward that finds them used sets them
+    itself: the first backward of a forward, a second one of the same forward (retain_graph) and a run with the forward's
+    side job switched off (gs_tuning "fwd_marks" = 0) all give the same bits.  The two-render step, whose second render
+    shares the first one's binning state, is covered by the same rule (its tests run with the default switches)."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_mi355 import _lib
+    dev = torch.device("cuda:0")
+    n, W, H = 8000, 320, 240
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=77, scale_mul=1.3)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def run(backwards):
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        leaves = (means3D, means2D, opac, kw["shs"], kw["scales"], kw["rotations"])
+        color, _ = dgr.GaussianRasterizer(_settings(cam, cloud, (0.1, 0.2, 0.3), dev))(means3D=means3D, means2D=means2D,
+                                                                                     opacities=opac, **kw)
+        out = []
+        for k in range(backwards):
+            for t in leaves:
+                t.grad = None
+            (color * gimg).sum().backward(retain_graph=k + 1 < backwards)
+            out.append([t.grad.clone() for t in leaves])
+        return color.detach().clone(), out
+
+    color, (first, second) = run(2)
+    assert all(float(g.abs().max()) > 0 for g in first[:3])
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    _lib.tuning("fwd_marks", 0)
+    try:
+        color0, (plain,) = run(1)
+    finally:
+        _lib.tuning("fwd_marks", 1)
+    assert torch.equal(color, color0)
+    for a, b in zip(first, plain):
+        assert torch.equal(a, b)
