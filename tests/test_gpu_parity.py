@@ -504,13 +504,16 @@ def test_tile_lists_across_tile_block_boundaries_with_screen_filling_gaussians(o
     _bulk_close(st["color"], fw["color"], frac=1e-4, name="color %dx%d" % (W, H))
 
 
-@pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths", "mostly-culled"])
+@pytest.mark.parametrize("case", ["one-depth", "half-one-depth", "far-outliers", "two-depths", "mostly-culled", "levels-240",
+                                  "levels-120", "levels-40", "levels-8", "clusters-120", "clusters-40"])
 def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
-    """The depth ranking is a bucket sort over the frame's key range (depth_sort.hip): ~128 keys per bucket when the
-    depths are evenly spread.  Uneven spreads must give the same bits through its other paths: a bucket beyond 4096 keys
-    (second launch, 128 KB of LDS), beyond 16384 (global-memory network), equal keys (ties in ascending index order), a
-    key range stretched by far outliers, most Gaussians culled (the bucket of those that touch no tile).  Checked: the ranking itself ((depth bits, index) ascending over the Gaussians
-    that touch a tile) and the tile lists against the oracle, bit for bit."""
+    """The depth ranking is a bucket sort over the frame's key range (depth_sort.hip): ~64 keys per bucket when the
+    depths are evenly spread, ranked by counting (one, two or four keys per lane up to 256 keys).  Uneven spreads must give
+    the same bits through its other paths: a wave's sorting network in LDS (up to 1024 keys), a bucket beyond that (second
+    launch, 128 KB of LDS), beyond 16384 (global-memory network), equal keys (ties in ascending index order), a key range
+    stretched by far outliers, most Gaussians culled (the bucket of those that touch no tile).  levels-K: K distinct depths
+    (24000 / K equal keys per bucket); clusters-K: K tight clusters of distinct keys.  Checked: the ranking itself ((depth
+    bits, index) ascending over the Gaussians that touch a tile) and the tile lists against the oracle, bit for bit."""
     from gsplat_mi355 import debug
     dev = torch.device("cuda:0")
     n, W, H = 24000, 256, 192
@@ -525,6 +528,12 @@ def test_depth_ranking_with_uneven_depth_distributions(oracle, case):
         cloud.xyz[40:, 2] = cloud.xyz[40:, 2] * 0.05                         # ... and the rest sits in 2 % of it
     elif case == "mostly-culled":
         cloud.xyz[torch.arange(n) % 10 < 7, 2] = -5.0  # 70 % behind the camera: the no-tile bucket, shared by many waves
+    elif case.startswith("levels-") or case.startswith("clusters-"):
+        k = int(case.split("-")[1])
+        level = torch.randint(0, k, (n,), generator=g).float()
+        cloud.xyz[:, 2] = -0.8 + 1.6 * level / k
+        if case.startswith("clusters-"):
+            cloud.xyz[:, 2] += torch.empty(n).uniform_(0.0, 1.6 / k * 0.05, generator=g)
     else:
         cloud.xyz[:, 2] = torch.where(torch.arange(n) % 3 == 0, torch.tensor(0.5), torch.tensor(-0.25))
     bg = (0.0, 0.0, 0.0)
