@@ -251,6 +251,13 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
             and colors_precomp.numel() and not colors_precomp.requires_grad and (sh is None or sh.numel() == 0)):
         dep = _second_render_dependency(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
     _tls.grad_mode = torch.is_grad_enabled()  # (inside Function.forward grad mode is always off)
+    if not _tls.grad_mode:
+        # no_grad (the reference's render loop, render.py:51-62): no autograd node would be built, and Function.apply
+        # costs ~10 us of Python per call for building none -- a tenth of a forward-only frame at 50k Gaussians
+        color, radii, opacity = _RasterizeGaussians.forward(_InferenceCtx(), means3D, means2D, sh, colors_precomp, opacities,
+                                                            scales, rotations, cov3Ds_precomp, raster_settings,
+                                                            bool(with_opacity), None)
+        return (color, radii, opacity) if with_opacity else (color, radii)
     color, radii, opacity = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                                        cov3Ds_precomp, raster_settings, bool(with_opacity), dep)
     return (color, radii, opacity) if with_opacity else (color, radii)
@@ -285,6 +292,20 @@ def _second_render_dependency(means3D, means2D, opacities, scales, rotations, co
     if e.key["scalars"] != key["scalars"] or e.key["sigs"] != key["sigs"]:
         return None
     return img1
+
+
+class _InferenceCtx(object):
+    """What _forward / _finish touch of an autograd context, for a call under no_grad: nothing is saved, no node exists."""
+    needs_input_grad = (False,) * 11
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -327,7 +348,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         W, H = int(raster_settings.image_width), int(raster_settings.image_height)
         keep = []
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             a = _make_args(raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                            keep)
             stream = torch.cuda.current_stream(dev)
@@ -478,7 +499,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         g = _f32c(grad_out_color, "grad_out_color")
         g_op = _f32c(grad_out_opacity, "grad_out_opacity") if (ctx.with_opacity and grad_out_opacity is not None) else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             a, _keep = ctx.fwd_args  # the forward's argument block: the same tensors (saved above), the same long_lists
             if (a.means3D != means3D.data_ptr() or a.opacities != opacities.data_ptr()
                     or (has_sh and a.shs != sh.data_ptr()) or (has_sr and a.scales != scales.data_ptr())):
