@@ -94,7 +94,7 @@ class _GeomCache(object):
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
                              float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT,
                              # the cached state is only valid in stream order: a hit must come from the same stream
-                             int(torch.cuda.current_stream(means3D.device).cuda_stream) if stream_handle is None
+                             _lib.stream_handle(means3D.device) if stream_handle is None
                              else int(stream_handle)),
                     sigs=[self._sig(t) for t in tensors],
                     # the objects themselves: an id() can only be trusted while its object is alive
@@ -351,13 +351,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         with _lib.on_device(dev):
             a = _make_args(raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                            keep)
-            stream = torch.cuda.current_stream(dev)
-            sptr = ctypes.c_void_p(stream.cuda_stream)
+            stream_h = _lib.stream_handle(dev)
+            sptr = ctypes.c_void_p(stream_h)
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
             # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
             share = _SHARE and getattr(_tls, "grad_mode", True) and any(ctx.needs_input_grad)
-            gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream.cuda_stream)
+            gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream_h)
                     if share else None)
             hit = _geom_cache.take(dev, gkey) if share else None
             if not share:
@@ -508,7 +508,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
                                scales if has_sr else None, rotations if has_sr else None,
                                cov3Ds_precomp if has_cov else None, _keep, long_lists=ctx.long_lists)
-            sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            sptr = _lib.stream_ptr(dev)
             scratch_bytes = _size("gs_backward_scratch_bytes", D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
             M = int(sh.shape[1]) if has_sh else 0
@@ -560,8 +560,8 @@ class GaussianRasterizer(nn.Module):
             out = torch.zeros(P, dtype=torch.uint8, device=pos.device)
             view = _f32c(rs.viewmatrix.to(pos.device), "viewmatrix")
             proj = _f32c(rs.projmatrix.to(pos.device), "projmatrix")
-            with torch.cuda.device(pos.device):
-                sptr = ctypes.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+            with _lib.on_device(pos.device):
+                sptr = _lib.stream_ptr(pos.device)
                 _lib.check(L.gs_mark_visible(P, pos.data_ptr(), view.data_ptr(), proj.data_ptr(), _lib.ptr(out), sptr))
         return out.bool()
 

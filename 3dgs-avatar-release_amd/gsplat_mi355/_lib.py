@@ -199,6 +199,25 @@ def on_device(dev):
     return _OnDevice(dev.index)
 
 
+_raw_stream = None
+
+
+def stream_handle(dev):
+    """The current HIP stream of `dev` as an integer handle (what torch.cuda.current_stream(dev).cuda_stream returns,
+    without building a Stream object and parsing the device: ~5 us per call, seven calls per training step)."""
+    global _raw_stream
+    import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream and dev.index is not None:
+        return int(_raw_stream(dev.index))
+    return int(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def stream_ptr(dev):
+    return c_void_p(stream_handle(dev))
+
+
 def ptr(t):
     """Device pointer of a tensor, or None (NULL = absent) for None / empty tensors."""
     if t is None or t.numel() == 0:

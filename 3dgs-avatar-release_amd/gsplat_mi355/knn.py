@@ -43,8 +43,8 @@ def knn_points(p1, p2, K=1, return_sorted=True, return_nn=False):
     dists = torch.empty(n1, K, dtype=torch.float32, device=qd.device)
     idx = torch.empty(n1, K, dtype=torch.int64, device=qd.device)
     ws = torch.empty(_lib.nbytes(L.knn_workspace_bytes, n2), dtype=torch.uint8, device=qd.device)
-    with torch.cuda.device(qd.device):
-        sptr = ctypes.c_void_p(torch.cuda.current_stream(qd.device).cuda_stream)
+    with _lib.on_device(qd.device):
+        sptr = _lib.stream_ptr(qd.device)
         _lib.check(L.knn_points(n1, _lib.ptr(qd), n2, _lib.ptr(rd), K, _lib.ptr(dists), _lib.ptr(idx), ws.data_ptr(),
                                 ws.numel(), sptr))
     nn = None

@@ -29,8 +29,8 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom)
     if tuple(viewspace_grad.shape) != (n, 3) or max_radii2D.numel() != n or xyz_gradient_accum.numel() != n or denom.numel() != n:
         raise ValueError("densify_stats: shapes do not match N = %d" % n)
     L = _lib.load()
-    with torch.cuda.device(radii.device):
-        sptr = ctypes.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)
+    with _lib.on_device(radii.device):
+        sptr = _lib.stream_ptr(radii.device)
         _lib.check(L.gs_densify_stats(n, _lib.ptr(radii), _lib.ptr(viewspace_grad), _lib.ptr(max_radii2D),
                                       _lib.ptr(xyz_gradient_accum), _lib.ptr(denom), sptr))
     _bump_versions(max_radii2D, xyz_gradient_accum, denom)
@@ -88,8 +88,8 @@ class FusedAdam(torch.optim.Optimizer):
                 arr = (_lib.GsAdamTensor * len(chunk))()
                 for k, (p, g, m, v, lr) in enumerate(chunk):
                     arr[k] = _lib.GsAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr)
-                with torch.cuda.device(dev):
-                    sptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                with _lib.on_device(dev):
+                    sptr = _lib.stream_ptr(dev)
                     _lib.check(L.gs_adam_step(len(chunk), arr, b1, b2, eps, step, sptr))
                 for p, _g, m, v, _lr in chunk:
                     _bump_versions(p, m, v)

@@ -23,7 +23,7 @@ def _dev32(t, name):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.stream_ptr(dev)
 
 
 class _BuildCovariance(torch.autograd.Function):
@@ -32,7 +32,7 @@ class _BuildCovariance(torch.autograd.Function):
         L = _lib.load()
         n = int(scaling.shape[0])
         cov = torch.empty(n, 6, dtype=torch.float32, device=scaling.device)
-        with torch.cuda.device(scaling.device):
+        with _lib.on_device(scaling.device):
             _lib.check(L.gs_build_covariance(n, _lib.ptr(scaling), float(scaling_modifier), _lib.ptr(rotation),
                                              1 if is_matrix else 0, _lib.ptr(cov), _stream(scaling.device)))
         ctx.save_for_backward(scaling, rotation)
@@ -47,7 +47,7 @@ class _BuildCovariance(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         ds = torch.empty_like(scaling)
         dr = torch.empty_like(rotation)
-        with torch.cuda.device(scaling.device):
+        with _lib.on_device(scaling.device):
             _lib.check(L.gs_build_covariance_backward(n, _lib.ptr(scaling), ctx.mod, _lib.ptr(rotation),
                                                       1 if ctx.is_matrix else 0, _lib.ptr(g), _lib.ptr(ds), _lib.ptr(dr),
                                                       _stream(scaling.device)))
@@ -78,7 +78,7 @@ class _Sh2Rgb(torch.autograd.Function):
         colors = torch.empty(n, 3, dtype=torch.float32, device=xyz.device)
         clamped = torch.empty(n, dtype=torch.uint8, device=xyz.device)
         noise_arr = (ctypes.c_float * 9)(*noise) if noise is not None else None
-        with torch.cuda.device(xyz.device):
+        with _lib.on_device(xyz.device):
             _lib.check(L.gs_sh2rgb(n, int(deg), m, _lib.ptr(features), _lib.ptr(xyz), _lib.ptr(campos),
                                    _lib.ptr(fwd_rot), noise_arr, _lib.ptr(colors), _lib.ptr(clamped), _stream(xyz.device)))
         ctx.save_for_backward(features, xyz, campos, fwd_rot if fwd_rot is not None else torch.empty(0, device=xyz.device),
@@ -95,7 +95,7 @@ class _Sh2Rgb(torch.autograd.Function):
         dsh = torch.empty_like(features)
         dxyz = torch.empty_like(xyz)
         noise_arr = (ctypes.c_float * 9)(*ctx.noise) if ctx.noise is not None else None
-        with torch.cuda.device(xyz.device):
+        with _lib.on_device(xyz.device):
             _lib.check(L.gs_sh2rgb_backward(n, ctx.deg, m, _lib.ptr(features), _lib.ptr(xyz), _lib.ptr(campos),
                                             _lib.ptr(fwd_rot) if ctx.has_rot else None, noise_arr, _lib.ptr(clamped),
                                             _lib.ptr(g), _lib.ptr(dsh), _lib.ptr(dxyz), _stream(xyz.device)))

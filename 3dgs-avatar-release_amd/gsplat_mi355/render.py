@@ -128,8 +128,8 @@ class _L1Loss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         ws = torch.empty(_lib.nbytes(L.gs_l1_loss_workspace_bytes, n), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
-            sptr = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with _lib.on_device(x.device):
+            sptr = _lib.stream_ptr(x.device)
             _lib.check(L.gs_l1_loss(n, x.data_ptr(), y.data_ptr(), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
                                     ws.numel(), sptr))
         ctx.save_for_backward(grad)
@@ -152,8 +152,8 @@ class _BceLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         ws = torch.empty(_lib.nbytes(L.gs_l1_loss_workspace_bytes, n), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
-            sptr = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with _lib.on_device(x.device):
+            sptr = _lib.stream_ptr(x.device)
             _lib.check(L.gs_bce_loss(n, x.data_ptr(), y.data_ptr(), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
                                      ws.numel(), sptr))
         ctx.save_for_backward(grad)
@@ -202,8 +202,8 @@ class _Ssim(torch.autograd.Function):
         need = img1.requires_grad
         maps = torch.empty((3, C, H, W), dtype=torch.float32, device=img1.device) if need else None
         ws = torch.empty(_lib.nbytes(L.gs_ssim_workspace_bytes, C, H, W), dtype=torch.uint8, device=img1.device)
-        with torch.cuda.device(img1.device):
-            sptr = ctypes.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)
+        with _lib.on_device(img1.device):
+            sptr = _lib.stream_ptr(img1.device)
             _lib.check(L.gs_ssim_forward(C, H, W, img1.data_ptr(), img2.data_ptr(), out.data_ptr(),
                                          _lib.ptr(maps[0]) if need else None, _lib.ptr(maps[1]) if need else None,
                                          _lib.ptr(maps[2]) if need else None, ws.data_ptr(), ws.numel(), sptr))
@@ -218,8 +218,8 @@ class _Ssim(torch.autograd.Function):
         C, H, W = (int(v) for v in img1.shape)
         grad = torch.empty_like(img1)
         g = g.to(torch.float32).contiguous()
-        with torch.cuda.device(img1.device):
-            sptr = ctypes.c_void_p(torch.cuda.current_stream(img1.device).cuda_stream)
+        with _lib.on_device(img1.device):
+            sptr = _lib.stream_ptr(img1.device)
             _lib.check(L.gs_ssim_backward(C, H, W, img1.data_ptr(), img2.data_ptr(), maps[0].data_ptr(),
                                           maps[1].data_ptr(), maps[2].data_ptr(), g.data_ptr(), grad.data_ptr(), sptr))
         return grad, None

@@ -17,6 +17,6 @@ def distCUDA2(points):
     with torch.cuda.device(pts.device):
         ws_bytes = _lib.nbytes(L.knn_workspace_bytes, P)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
-        sptr = ctypes.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream)
+        sptr = _lib.stream_ptr(pts.device)
         _lib.check(L.knn_dist2(P, _lib.ptr(pts), _lib.ptr(out), ws.data_ptr(), ws_bytes, sptr))
     return out
