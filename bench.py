@@ -47,6 +47,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (spec)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD-32 for 2 cycles
+MEASURED_VALU_CLOCK_HZ = 2.07e9  # shader clock under a VALU-bound kernel (see roofline.binding)
 
 WORKLOADS = {
     # name: (N, W, H, sh_degree, heavy_tail, backward)
@@ -532,7 +533,12 @@ def main(argv=None):
         if dominant in valu and "issue_slot_util" in valu[dominant]:
             # the ceiling that actually binds the dominant kernel, next to the HBM one the contract asks for
             roof["binding"] = {"ceiling": "VALU issue slots (one wave64 instruction per SIMD-32 every 2 cycles)",
-                               "frac": valu[dominant]["issue_slot_util"], "kernel": dominant}
+                               "frac": valu[dominant]["issue_slot_util"], "kernel": dominant,
+                               # the chip does not hold 2.4 GHz under a VALU-bound load: s_memtime against s_memrealtime
+                               # reads 2.07 GHz in an FMA stream and in the forward's loop (tools/valu_rate.hip,
+                               # tools/fwd_two_pixel.hip; a builder-measured constant, not taken live)
+                               "measured_clock_hz": MEASURED_VALU_CLOCK_HZ,
+                               "frac_at_measured_clock": round(valu[dominant]["issue_slot_util"] * CLOCK_HZ / MEASURED_VALU_CLOCK_HZ, 4)}
         roof["valu"] = {"peak_tflops": VALU_PEAK_TFLOPS, "simds": SIMDS, "clock_hz": CLOCK_HZ,
                         "note": "secondary ceiling (SURVEY.md 8d): the render kernels are VALU-issue bound, not HBM bound; "
                                 "issue_slot_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
