@@ -155,10 +155,10 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         // reference's tie order); the ranking ends in v0 and, with what binning needs of every Gaussian, in the rank list
         if (gs_tune_get(GS_TUNE_DEPTH_SORT)) {
             StageScope sc_("depth_sort", s);  // the numbering rides in its first launch, the rank list in its last ones
-            const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_pre),
+            const DepthSortState st{(unsigned long long*)(g + L.ds_tmp), (unsigned long long*)(g + L.ds_tmp2),
+                                    (uint32_t*)(g + L.ds_cnt), (uint32_t*)(g + L.ds_pre),
                                     (uint32_t*)(g + L.ds_tot),
-                                    (uint32_t*)(g + L.ds_loc), (uint32_t*)(g + L.ds_grp), (uint32_t*)(g + L.ds_range),
-                                    (uint32_t*)(g + L.ds_big), L.ds_nb,
+                                    (uint32_t*)(g + L.ds_loc), (uint32_t*)(g + L.ds_grp), (uint32_t*)(g + L.ds_range), L.ds_nb,
                                     L.ds_blocks};
             const PairNumbering pn{(const uint32_t*)(g + L.tiles), (const uint32_t*)(g + L.wsum), (float*)(g + L.rec), count, poll,
                                    (uint32_t*)(g + L.chunk_pairs), (a->P + 255) / 256};

@@ -40,7 +40,7 @@ static inline int ds_buckets(int P) {
 
 struct GeomLayout {
     size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, wkmin, wkmax, hist, count,
-        ds_tmp, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, ds_big, total;
+        ds_tmp, ds_tmp2, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, total;
     int nblk_sort, nwaves, ds_nb, ds_blocks;
 };
 static inline GeomLayout geom_layout(int P) {
@@ -69,13 +69,13 @@ static inline GeomLayout geom_layout(int P) {
     L.ds_nb = ds_buckets(P);
     L.ds_blocks = (int)((n + DS_ITEMS - 1) / DS_ITEMS);
     L.ds_tmp = take(n * 8);                                        // (key << 32 | index), bucket after bucket
+    L.ds_tmp2 = take(n * 8);                                       // ... and sub-bucket after sub-bucket (a bucket beyond 4096)
     L.ds_cnt = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // [block][bucket] counts ...
     L.ds_pre = take((size_t)L.ds_blocks * (L.ds_nb + 1) * 4);      // ... and their exclusive prefix over the blocks
     L.ds_tot = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_loc = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_grp = take((size_t)((L.ds_nb + 1 + 63) / 64) * 4);
-    L.ds_range = take(16);                                         // key range (3 words) + the number of large buckets
-    L.ds_big = take((size_t)(L.ds_nb + 1) * 4);                    // the buckets too large for a wave, in any order
+    L.ds_range = take(16);
     L.total = o;
     return L;
 }
@@ -309,7 +309,7 @@ int launch_preprocess(const GsFwdArgs& a, float* rec, float* depths, uint32_t* t
                       uint32_t* sort_keys, uint32_t* sort_vals, int32_t* radii, uint32_t* wave_tiles, uint32_t* wave_kmin,
                       uint32_t* wave_kmax, ZeroJob zero, ZeroJob zero2, hipStream_t s);
 // bucket depth sort (depth_sort.hip): sorted_idx = the Gaussian indices in ascending (depth key, index) order
-struct DepthSortState { unsigned long long* tmp; uint32_t *cnt, *pre, *tot, *loc, *grp, *range, *big; int nb, blocks; };
+struct DepthSortState { unsigned long long *tmp, *tmp2; uint32_t *cnt, *pre, *tot, *loc, *grp, *range; int nb, blocks; };
 // pair numbering done by the sort's first launch (see first_pair_kernel, which the radix path uses) and the rank list
 // written by its last ones (see rank_list_kernel, likewise)
 struct PairNumbering { const uint32_t *tiles, *wave_tiles; float* rec; unsigned long long *count, *host_count; uint32_t* chunk_pairs; int nchunks; };

@@ -2,20 +2,22 @@
 // "stable sort of (tile << 32 | depth_bits) keys" (binning.hip is the second half).
 //
 // A bucket sort, four launches instead of the twelve of a 4 x 8-bit LSD radix sort over the same 200k keys (which is
-// nothing but launch latency: 1.6 MB of keys, ~4.7 us per launch).  Keys are positive float bits, so they order like the
-// depths.  (1) count: every key goes to bucket floor(NB (key - kmin) / (kmax - kmin + 1)) -- kmin / kmax of the frame from
-// the per-wave ranges the preprocess kernel left -- per-workgroup counts in LDS; Gaussians that touch no tile go to an
+// nothing but launch latency: 1.6 MB of keys, ~4.7 us per launch in a frame's trace).  Keys are positive float bits, so
+// they order like the depths.  (1) count: every key goes to a bucket by a linear map of [kmin, kmax] -- the frame's range,
+// from the per-wave ranges the preprocess kernel left -- per-workgroup counts in LDS; Gaussians that touch no tile go to an
 // extra bucket behind all others (nothing downstream looks at their order).  (2) prefix: per bucket over the workgroups,
-// and over the buckets.  (3) scatter: (key << 32 | index) to the bucket's slice, any order inside it.  (4) one workgroup
-// per bucket sorts its slice (bitonic network on the 64-bit composites in LDS): equal keys end up in ascending index
-// order, i.e. the order of a STABLE sort on the key.  NB ~ P / 64 buckets (at most 4096): a bucket holds ~64 keys for a uniform
-// spread of depths; one that holds more than the LDS takes (a scene with most Gaussians at one depth) is sorted in
-// global memory by the same network -- slow (milliseconds for 200k keys in one bucket) but exact.
+// and over the buckets.  (3) scatter: (key << 32 | index) to the bucket's slice, any order inside it.  (4) a WAVE per
+// bucket puts its slice in order -- the composites are distinct and equal keys end up in ascending index order, i.e. the
+// order of a STABLE sort on the key -- and emits the rank records.  NB ~ P / 64 buckets (at most 4096): a bucket holds ~64
+// keys for a uniform spread of depths (ranked by counting, no network); unevenly spread depths go down the other paths
+// of the same launch: a wave's bitonic network (up to 1024), the workgroup's (up to 4096), sub-buckets by sampling
+// (beyond).  All of these kernels are chains of dependent round trips, not bandwidth: see DESIGN.md 5.2.
 #include "common.h"
 
 #define DS_THREADS 256
-#define DS_CAP_BIG 16384   // composites a 256-thread workgroup sorts in LDS (128 KB): second launch, for unevenly spread depths
-#define DS_WAVE_CAP 1024   // composites one wave sorts in LDS: the first launch
+#define DS_WAVE_CAP 1024   // composites one wave sorts in its quarter of the workgroup's LDS
+#define DS_WG_BUCKETS 4    // buckets (waves) per workgroup of the bucket launch
+#define DS_CAP_BIG (DS_WG_BUCKETS * DS_WAVE_CAP)  // composites the whole workgroup sorts in LDS (32 KB): a bucket too large for a wave
 
 // Bucket of a key: floor((key - kmin) * scale / 2^32) with scale = floor(nb * 2^32 / span), span = kmax - kmin + 1 -- a
 // non-decreasing map of [kmin, kmax] onto [0, nb) that costs a 32 x 64-bit multiply per key (the exact quotient
@@ -105,7 +107,6 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
         krange[0] = kmin;
         krange[1] = (uint32_t)scale;
         krange[2] = (uint32_t)(scale >> 32);
-        krange[3] = 0u;  // large buckets found by the prefix pass
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const unsigned long long total = block_base + s_wave[WPB];
@@ -135,8 +136,7 @@ __global__ __launch_bounds__(DS_THREADS) void ds_count_kernel(const uint32_t* __
 #define DSP_ROWS 32
 __global__ __launch_bounds__(256) void ds_prefix_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ pre,
                                                         uint32_t* __restrict__ tot, uint32_t* __restrict__ loc,
-                                                        uint32_t* __restrict__ grp, uint32_t* __restrict__ nbig,
-                                                        uint32_t* __restrict__ big, int nbp, int blocks) {
+                                                        uint32_t* __restrict__ grp, int nbp, int blocks) {
     __shared__ uint32_t s_part[4][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + lane;
@@ -173,8 +173,6 @@ __global__ __launch_bounds__(256) void ds_prefix_kernel(const uint32_t* __restri
     }
     if (wid == 0) {
         if (live) tot[b] = total;
-        // the buckets the wave-per-bucket launch leaves to the next one (normally none), in any order
-        if (live && b != nbp - 1 && total > DS_WAVE_CAP) big[atomicAdd(nbig, 1u)] = (uint32_t)b;
         const uint32_t x = wave_scan_incl(live ? total : 0u);
         if (live) loc[b] = x - total;
         if (lane == 63) grp[blockIdx.x] = x;
@@ -246,9 +244,9 @@ __device__ __forceinline__ void ds_bitonic(const long long n, LOAD load, STORE s
     long long n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
     const long long half = n_pad >> 1;
-    for (long long k = 2; k <= n_pad; k <<= 1) {
+    for (long long k = 2, lk = 0; k <= n_pad; k <<= 1, lk++) {  // lk = log2(k / 2)
         for (long long t = threadIdx.x; t < half; t += DS_THREADS) {  // flip step
-            const long long blk = t / (k >> 1), off = t % (k >> 1);
+            const long long blk = t >> lk, off = t & ((k >> 1) - 1);
             const long long i = blk * k + off, p = blk * k + (k - 1 - off);
             if (p < n) {
                 const unsigned long long a = load(i), c = load(p);
@@ -359,33 +357,16 @@ __device__ __forceinline__ void ds_small_bucket(const unsigned long long* __rest
     }
 }
 
-// One WAVE per bucket for the buckets of up to DS_WAVE_CAP composites (all of them when the depths are evenly spread: ~64
-// per bucket): the network runs in LDS without workgroup barriers -- a wave's LDS operations execute in order.
-__global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned long long* __restrict__ tmp,
-                                                                 const uint32_t* __restrict__ tot,
-                                                                 const uint32_t* __restrict__ loc,
-                                                                 const uint32_t* __restrict__ grp, int nb,
-                                                                 const RankOut ro) {
-    __shared__ unsigned long long s[DS_WAVE_CAP];
-    const int lane = threadIdx.x;
-    // bucket; bucket nb holds the Gaussians that touch no tile and is shared by the workgroups nb, nb + 1, ...
-    const int b = min((int)blockIdx.x, nb);
-    // (all three requested before the first is looked at; nb <= 4096: at most 64 groups before a bucket's own)
-    const int n = (int)tot[b];
-    const uint32_t in_group = loc[b];
-    uint32_t part = lane < (b >> 6) ? grp[lane] : 0u;
-    if (n == 0 || (n > DS_WAVE_CAP && b != nb)) return;  // (larger buckets: ds_bucket_sort_kernel)
-    const uint32_t start = wave_sum(part) + in_group;
-    const unsigned long long* seg = tmp + start;
-    ChunkAcc acc;
-    if (b == nb) {
-        // no order needed among the Gaussians that touch no tile (every later stage skips them)
-        for (int i0 = ((int)blockIdx.x - nb) * 64; i0 < n; i0 += ((int)gridDim.x - nb) * 64) {
-            const int i = i0 + lane;
-            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)seg[i] : 0u, false, acc);
-        }
-        return;
-    }
+// The bucket launch: one WAVE per bucket, four buckets per workgroup.  A bucket of up to DS_WAVE_CAP composites (all of them
+// when the depths are evenly spread: ~64 per bucket) is the wave's own business, in its quarter of the workgroup's LDS and
+// without workgroup barriers -- a wave's LDS operations execute in order: up to 256 composites by counting
+// (ds_small_bucket), more by a bitonic network.  A larger bucket is left for the whole workgroup, behind the one barrier
+// of the common case: up to DS_CAP_BIG composites in the four quarters together, more in global memory (slow, exact).
+// (Until round 3 the large buckets had a launch of their own with 128 KB of LDS per workgroup: empty for evenly spread
+// depths, and 4.7 us in the trace of every frame.)
+__device__ __forceinline__ void ds_wave_bucket(const unsigned long long* __restrict__ seg, unsigned long long* s, int n,
+                                               uint32_t start, const RankOut& ro) {
+    const int lane = threadIdx.x & 63;
     if (n <= 64) { ds_small_bucket<1>(seg, s, n, start, ro); return; }  // (wave-uniform)
     if (n <= 128) { ds_small_bucket<2>(seg, s, n, start, ro); return; }
     if (n <= 256) { ds_small_bucket<4>(seg, s, n, start, ro); return; }
@@ -420,6 +401,7 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
             step_done();
         }
     }
+    ChunkAcc acc;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
         rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
@@ -427,60 +409,163 @@ __global__ __launch_bounds__(64) void ds_bucket_sort_wave_kernel(const unsigned 
     chunk_flush(ro, acc);
 }
 
-// The buckets of more than DS_WAVE_CAP composites (the list the prefix pass made; normally empty, and the few workgroups of
-// this launch leave at once).  One workgroup per bucket and trip: up to CAP composites are sorted in LDS, more in global memory.
-template <int CAP>
-__global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned long long* __restrict__ tmp,
-                                                                    const uint32_t* __restrict__ tot,
-                                                                    const uint32_t* __restrict__ loc,
-                                                                    const uint32_t* __restrict__ grp,
-                                                                    const uint32_t* __restrict__ nbig,
-                                                                    const uint32_t* __restrict__ big, const RankOut ro) {
-    __shared__ unsigned long long s[CAP];
-    __shared__ uint32_t s_grp[4];
+// (the whole workgroup; every thread calls it)
+__device__ __forceinline__ void ds_large_bucket(unsigned long long* __restrict__ seg, unsigned long long* s, int n,
+                                                uint32_t start, const RankOut& ro) {
     const int tid = threadIdx.x;
-    const int count = (int)*nbig;
-    for (int j = blockIdx.x; j < count; j += gridDim.x) {  // (workgroup-uniform)
-        const int b = (int)big[j];
-        const int n = (int)tot[b];
-        // first slot of this bucket: the groups before its own + its prefix inside the group
-        {
-            const int g = b >> 6;
-            uint32_t part = 0;
-            for (int q = tid; q < g; q += DS_THREADS) part += grp[q];
-            part = wave_sum(part);
-            __syncthreads();  // (the trip before has read s_grp and s)
-            if ((tid & 63) == 0) s_grp[tid >> 6] = part;
-            __syncthreads();
-        }
-        const uint32_t start = s_grp[0] + s_grp[1] + s_grp[2] + s_grp[3] + loc[b];
-        unsigned long long* seg = tmp + start;
-        ChunkAcc acc;
-        if (n <= CAP) {
-            for (int i = tid; i < n; i += DS_THREADS) s[i] = seg[i];
-            __syncthreads();
-            ds_bitonic(n, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
-                       [&]() { __syncthreads(); });
-            for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
-                const int i = i0 + tid;
-                rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
-            }
-            chunk_flush(ro, acc);
-            continue;
-        }
-        // A bucket larger than the LDS takes (most of the scene at one depth): the same network in global memory, by this
-        // workgroup alone.  The elements go through agent-scope (L2) accesses and every stage ends with a device fence, so
-        // that a wave reads what another wave of the workgroup stored in the stage before.  Slow, exact.
-        ds_bitonic(n,
-                   [&](long long i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-                   [&](long long i, unsigned long long v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-                   [&]() { __threadfence(); __syncthreads(); });
+    ChunkAcc acc;
+    if (n <= DS_CAP_BIG) {
+        for (int i = tid; i < n; i += DS_THREADS) s[i] = seg[i];
+        __syncthreads();
+        ds_bitonic(n, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
+                   [&]() { __syncthreads(); });
         for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
             const int i = i0 + tid;
-            rank_emit(ro, start + i, i < n,
-                      i < n ? (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, true, acc);
+            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)s[i] : 0u, true, acc);
         }
         chunk_flush(ro, acc);
+        return;
+    }
+    // A bucket larger than the LDS takes (much of the scene at one depth): the same network in global memory, by this
+    // workgroup alone.  The elements go through agent-scope (L2) accesses and every stage ends with a device fence, so
+    // that a wave reads what another wave of the workgroup stored in the stage before.  Slow, exact.
+    ds_bitonic(n,
+               [&](long long i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+               [&](long long i, unsigned long long v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+               [&]() { __threadfence(); __syncthreads(); });
+    for (int i0 = 0; i0 < n; i0 += DS_THREADS) {
+        const int i = i0 + tid;
+        rank_emit(ro, start + i, i < n,
+                  i < n ? (uint32_t)__hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, true, acc);
+    }
+    chunk_flush(ro, acc);
+}
+
+// A bucket beyond DS_CAP_BIG composites (a key range stretched by far outliers, or much of the scene at one depth): the
+// workgroup buckets it once more, by SAMPLING -- 1024 of its composites (key << 32 | index: all distinct), sorted in LDS,
+// give the splitters of ~64-composite sub-buckets whose sizes are balanced whatever the distribution (a linear map of
+// the composites, tried first, puts 12 000 equal keys among a few hundred distinct ones into ONE sub-bucket); every
+// composite finds its sub-bucket by a binary search over the splitters, is counted and scattered through LDS counters
+// into a second array, and the four waves then take the sub-buckets like buckets of the launch.  A sub-bucket still too
+// large for a wave is sorted by the whole workgroup (ds_large_bucket).  (Until round 3: a bitonic network in global
+// memory for the whole bucket -- 1.0 ms for 12 000 composites; ds_large_bucket still ends that way beyond 4096.)
+#define DS_SUB_MAX 1024  // (4 KB of counters: with the 32 KB of composites four workgroups still fit a CU)
+#define DS_SAMPLE 1024
+__device__ __forceinline__ void ds_giant_bucket(unsigned long long* __restrict__ seg, unsigned long long* __restrict__ seg2,
+                                                unsigned long long* s, uint32_t* s_sub, int n, uint32_t start,
+                                                const RankOut& ro) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nsub = min(DS_SUB_MAX, max(2, n / 64));
+    static_assert(DS_SAMPLE <= DS_CAP_BIG / 2, "the sample sits in the front of s, the scan's words behind it");
+    for (int i = tid; i < DS_SAMPLE; i += DS_THREADS) s[i] = seg[(long long)i * n / DS_SAMPLE];  // (n > DS_CAP_BIG >= DS_SAMPLE)
+    for (int k = tid; k <= nsub; k += DS_THREADS) s_sub[k] = 0u;
+    __syncthreads();
+    ds_bitonic(DS_SAMPLE, [&](long long i) { return s[i]; }, [&](long long i, unsigned long long v) { s[i] = v; },
+               [&]() { __syncthreads(); });
+    // splitter j (j = 0 .. nsub - 2) = sample[(j + 1) DS_SAMPLE / nsub - 1]; sub-bucket of c = the number of splitters below c
+    auto sub_of = [&](unsigned long long c) {
+        int lo = 0, hi = nsub - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s[(mid + 1) * DS_SAMPLE / nsub - 1] < c) lo = mid + 1; else hi = mid;
+        }
+        return lo;  // (non-decreasing in c)
+    };
+    for (int i = tid; i < n; i += DS_THREADS) atomicAdd(&s_sub[sub_of(seg[i])], 1u);
+    __syncthreads();
+    // exclusive prefix of the counts: DS_SUB_MAX / DS_THREADS consecutive counters per thread, a wave scan, the waves' sums
+    {
+        constexpr int PER = DS_SUB_MAX / DS_THREADS;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) { c[u] = tid * PER + u < nsub ? s_sub[tid * PER + u] : 0u; sum += c[u]; }
+        const uint32_t incl = wave_scan_incl(sum);
+        __syncthreads();  // (all counts are in registers)
+        uint32_t* s_w = reinterpret_cast<uint32_t*>(s + DS_SAMPLE);  // (behind the sample, which the scatter still reads)
+        if (lane == 63) s_w[wid] = incl;
+        __syncthreads();
+        uint32_t before = incl - sum;
+        for (int w = 0; w < wid; w++) before += s_w[w];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (tid * PER + u < nsub) s_sub[tid * PER + u] = before;
+            before += c[u];
+        }
+        __syncthreads();
+    }
+    // scatter: afterwards s_sub[k] is the END of sub-bucket k (its start is the end of k - 1)
+    for (int i = tid; i < n; i += DS_THREADS) {
+        const unsigned long long c = seg[i];
+        seg2[atomicAdd(&s_sub[sub_of(c)], 1u)] = c;
+    }
+    __threadfence();  // (waves of this workgroup read what other waves of it stored)
+    __syncthreads();
+    for (int k = wid; k < nsub; k += DS_WG_BUCKETS) {  // (wave-uniform)
+        const uint32_t b0 = k ? s_sub[k - 1] : 0u, m = s_sub[k] - b0;
+        if (m > 0u && m <= (uint32_t)DS_WAVE_CAP) ds_wave_bucket(seg2 + b0, s + wid * DS_WAVE_CAP, (int)m, start + b0, ro);
+    }
+    __syncthreads();
+    for (int k = 0; k < nsub; k++) {  // (workgroup-uniform) the sub-buckets left over: normally none
+        const uint32_t b0 = k ? s_sub[k - 1] : 0u, m = s_sub[k] - b0;
+        if (m > (uint32_t)DS_WAVE_CAP) {
+            ds_large_bucket(seg2 + b0, s, (int)m, start + b0, ro);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(DS_THREADS) void ds_bucket_sort_kernel(unsigned long long* __restrict__ tmp,
+                                                                    unsigned long long* __restrict__ tmp2,
+                                                                    const uint32_t* __restrict__ tot,
+                                                                    const uint32_t* __restrict__ loc,
+                                                                    const uint32_t* __restrict__ grp, int nb,
+                                                                    const RankOut ro) {
+    __shared__ unsigned long long s[DS_CAP_BIG];
+    __shared__ uint32_t s_sub[DS_SUB_MAX + 1];      // (ds_giant_bucket)
+    __shared__ uint32_t s_large[DS_WG_BUCKETS][2];  // per wave: size and first slot of a bucket left for the workgroup (0: none)
+    static_assert(DS_THREADS == 64 * DS_WG_BUCKETS && DS_CAP_BIG == DS_WG_BUCKETS * DS_WAVE_CAP, "a wave and a quarter of the LDS per bucket");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int bucket_wgs = (nb + DS_WG_BUCKETS - 1) / DS_WG_BUCKETS;
+    if ((int)blockIdx.x >= bucket_wgs) {  // (workgroup-uniform)
+        // Bucket nb: the Gaussians that touch no tile, shared by the waves of the workgroups behind the buckets' own.  No
+        // order needed among them (every later stage skips them).
+        const int n = (int)tot[nb];
+        const uint32_t in_group = loc[nb];
+        const uint32_t part = lane < (nb >> 6) ? grp[lane] : 0u;
+        const uint32_t start = wave_sum(part) + in_group;
+        const unsigned long long* seg = tmp + start;
+        const int w = ((int)blockIdx.x - bucket_wgs) * DS_WG_BUCKETS + wid, nw = ((int)gridDim.x - bucket_wgs) * DS_WG_BUCKETS;
+        ChunkAcc acc;
+        for (int i0 = w * 64; i0 < n; i0 += nw * 64) {
+            const int i = i0 + lane;
+            rank_emit(ro, start + i, i < n, i < n ? (uint32_t)seg[i] : 0u, false, acc);
+        }
+        return;
+    }
+    const int b = (int)blockIdx.x * DS_WG_BUCKETS + wid;  // this wave's bucket
+    int n = 0;
+    uint32_t start = 0;
+    if (b < nb) {  // (wave-uniform)
+        // (all three requested before the first is looked at; nb <= 4096: at most 64 groups before a bucket's own)
+        n = (int)tot[b];
+        const uint32_t in_group = loc[b];
+        const uint32_t part = lane < (b >> 6) ? grp[lane] : 0u;
+        start = wave_sum(part) + in_group;
+    }
+    const bool large = n > DS_WAVE_CAP;
+    if (lane == 0) {
+        s_large[wid][0] = large ? (uint32_t)n : 0u;
+        s_large[wid][1] = start;
+    }
+    if (n > 0 && !large) ds_wave_bucket(tmp + start, s + wid * DS_WAVE_CAP, n, start, ro);
+    __syncthreads();
+    for (int w = 0; w < DS_WG_BUCKETS; w++) {
+        const int nl = (int)s_large[w][0];  // (workgroup-uniform)
+        if (nl) {
+            if (nl > DS_CAP_BIG) ds_giant_bucket(tmp + s_large[w][1], tmp2 + s_large[w][1], s, s_sub, nl, s_large[w][1], ro);
+            else ds_large_bucket(tmp + s_large[w][1], s, nl, s_large[w][1], ro);
+            __syncthreads();  // (s is the next one's)
+        }
     }
 }
 
@@ -492,20 +577,17 @@ int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uin
     hipLaunchKernelGGL(ds_count_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_count, s, keys, wave_kmin, wave_kmax, nwaves, P,
                        st.nb, st.cnt, st.range, pn);
     GS_LAUNCH_CHECK("depth_sort.count", debug, s);
-    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(256), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp,
-                       st.range + 3, st.big, nbp, st.blocks);
+    hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(256), 0, s, st.cnt, st.pre, st.tot, st.loc, st.grp, nbp,
+                       st.blocks);
     GS_LAUNCH_CHECK("depth_sort.prefix", debug, s);
     hipLaunchKernelGGL(ds_scatter_kernel, dim3(st.blocks), dim3(DS_THREADS), lds_scatter, s, keys, st.range, P, st.nb, st.pre,
                        st.loc, st.grp, st.tmp);
     GS_LAUNCH_CHECK("depth_sort.scatter", debug, s);
-    // a wave per bucket for the buckets of up to DS_WAVE_CAP composites (all of them unless the depths are very unevenly
-    // spread), then the larger ones with 128 KB of LDS per workgroup (its workgroups leave at once when there is none)
-    const int helpers = P / 1024 < 1 ? 1 : (P / 1024 > 512 ? 512 : P / 1024);  // waves sharing the no-tile bucket
-    hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(st.nb + helpers), dim3(64), 0, s, st.tmp, st.tot, st.loc, st.grp, st.nb, ro);
+    // a wave per bucket, four per workgroup (which takes the buckets too large for a wave together); behind them the
+    // workgroups whose waves share the bucket of the Gaussians that touch no tile
+    const int helpers = P / 4096 < 1 ? 1 : (P / 4096 > 128 ? 128 : P / 4096);
+    hipLaunchKernelGGL(ds_bucket_sort_kernel, dim3((st.nb + DS_WG_BUCKETS - 1) / DS_WG_BUCKETS + helpers), dim3(DS_THREADS), 0, s,
+                       st.tmp, st.tmp2, st.tot, st.loc, st.grp, st.nb, ro);
     GS_LAUNCH_CHECK("depth_sort.buckets", debug, s);
-    const int big_wgs = nbp < 64 ? nbp : 64;
-    hipLaunchKernelGGL(ds_bucket_sort_kernel<DS_CAP_BIG>, dim3(big_wgs), dim3(DS_THREADS), 0, s, st.tmp, st.tot, st.loc, st.grp,
-                       st.range + 3, st.big, ro);
-    GS_LAUNCH_CHECK("depth_sort.big_buckets", debug, s);
     return GS_OK;
 }

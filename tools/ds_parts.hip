@@ -24,7 +24,8 @@ static float time_us(F launch, int reps = 200) {
 }
 __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 0; }
 
-// the wave-per-bucket kernel with parts left out.  PART: 1 = no sorting network, 2 = no rank records, 3 = neither
+// the wave-per-bucket kernel as it was before the ranking by counting (a bitonic network for every bucket), with parts left
+// out.  PART: 1 = no sorting network, 2 = no rank records, 3 = neither, + 4 = no chunk sums, + 8 = no gathers
 template <int PART>
 __global__ __launch_bounds__(64) void wave_parts_kernel(const unsigned long long* __restrict__ tmp, const uint32_t* __restrict__ tot,
                                                         const uint32_t* __restrict__ loc, const uint32_t* __restrict__ grp, int nb,
@@ -109,13 +110,13 @@ int main(int argc, char** argv) {
         wmax[i / 64] = keys[i] > wmax[i / 64] ? keys[i] : wmax[i / 64];
     }
     uint32_t *d_keys, *d_tiles, *d_wsum, *d_wmin, *d_wmax, *d_cnt, *d_pre, *d_tot, *d_loc, *d_grp, *d_range, *d_big, *d_chunk, *d_sorted;
-    float* d_rec; unsigned long long *d_count, *d_tmp; uint4* d_rank;
+    float* d_rec; unsigned long long *d_count, *d_tmp, *d_tmp2; uint4* d_rank;
     (void)hipMalloc(&d_keys, P * 4); (void)hipMalloc(&d_tiles, P * 4); (void)hipMalloc(&d_wsum, nwaves * 4);
     (void)hipMalloc(&d_wmin, nwaves * 4); (void)hipMalloc(&d_wmax, nwaves * 4);
     (void)hipMalloc(&d_cnt, (size_t)blocks * nbp * 4); (void)hipMalloc(&d_pre, (size_t)blocks * nbp * 4);
     (void)hipMalloc(&d_tot, nbp * 4); (void)hipMalloc(&d_loc, nbp * 4); (void)hipMalloc(&d_grp, 66 * 4); (void)hipMalloc(&d_range, 16);
     (void)hipMalloc(&d_big, nbp * 4); (void)hipMalloc(&d_chunk, (P / 256 + 2) * 4); (void)hipMalloc(&d_sorted, P * 4);
-    (void)hipMalloc(&d_rec, (size_t)P * REC_F * 4); (void)hipMalloc(&d_count, 64); (void)hipMalloc(&d_tmp, (size_t)P * 8);
+    (void)hipMalloc(&d_rec, (size_t)P * REC_F * 4); (void)hipMalloc(&d_count, 64); (void)hipMalloc(&d_tmp, (size_t)P * 8); (void)hipMalloc(&d_tmp2, (size_t)P * 8);
     (void)hipMalloc(&d_rank, (size_t)P * 16);
     (void)hipMemset(d_rec, 0, (size_t)P * REC_F * 4);
     (void)hipMemcpy(d_keys, keys.data(), P * 4, hipMemcpyHostToDevice); (void)hipMemcpy(d_tiles, tiles.data(), P * 4, hipMemcpyHostToDevice);
@@ -137,15 +138,14 @@ int main(int argc, char** argv) {
     printf("ds_count, 256 buckets (small count rows)       %6.2f us\n", time_us([&] { count(nwaves, 256, pn, P); }));
     printf("ds_count, one workgroup's keys only (P = 2048) %6.2f us\n", time_us([&] { count(32, nb, pn, 2048); }));
     // the whole chain, launch after launch as the library issues it
-    auto prefix = [&] { hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(256), 0, 0, d_cnt, d_pre, d_tot, d_loc, d_grp, d_range + 3, d_big, nbp, blocks); };
+    auto prefix = [&] { hipLaunchKernelGGL(ds_prefix_kernel, dim3((nbp + 63) / 64), dim3(256), 0, 0, d_cnt, d_pre, d_tot, d_loc, d_grp, nbp, blocks); };
     auto scatter = [&] { hipLaunchKernelGGL(ds_scatter_kernel, dim3(blocks), dim3(DS_THREADS), lds_scatter, 0, d_keys, d_range, P, nb, d_pre, d_loc, d_grp, d_tmp); };
-    const int helpers = P / 1024 < 1 ? 1 : (P / 1024 > 512 ? 512 : P / 1024);
-    auto waves = [&] { hipLaunchKernelGGL(ds_bucket_sort_wave_kernel, dim3(nb + helpers), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); };
-    auto bigs = [&] { hipLaunchKernelGGL((ds_bucket_sort_kernel<DS_CAP_BIG>), dim3(64), dim3(DS_THREADS), 0, 0, d_tmp, d_tot, d_loc, d_grp, d_range + 3, d_big, ro); };
+    const int helpers = P / 4096 < 1 ? 1 : (P / 4096 > 128 ? 128 : P / 4096);
+    auto waves = [&] { hipLaunchKernelGGL(ds_bucket_sort_kernel, dim3((nb + DS_WG_BUCKETS - 1) / DS_WG_BUCKETS + helpers), dim3(DS_THREADS), 0, 0, d_tmp, d_tmp2, d_tot, d_loc, d_grp, nb, ro); };
     count(nwaves, nb, pn, P); prefix(); scatter(); (void)hipDeviceSynchronize();
     printf("ds_prefix                                      %6.2f us\n", time_us(prefix));
     printf("ds_scatter                                     %6.2f us\n", time_us(scatter));
-    printf("ds_bucket_sort_wave                            %6.2f us\n", time_us(waves));
+    printf("ds_bucket_sort (a wave per bucket)             %6.2f us\n", time_us(waves));
     printf("  ... without the sorting network             %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<1>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
     printf("  ... without the rank records                 %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<2>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
     printf("  ... with neither                             %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<3>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
@@ -153,8 +153,7 @@ int main(int argc, char** argv) {
     printf("  ... no network, records without gathers      %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<9>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
     printf("  ... no network, stores only                  %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<13>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
     printf("  ... all of it (copy of the product kernel)   %6.2f us\n", time_us([&] { hipLaunchKernelGGL(wave_parts_kernel<0>, dim3(nb), dim3(64), 0, 0, d_tmp, d_tot, d_loc, d_grp, nb, ro); }));
-    printf("ds_bucket_sort<big>, nothing to do             %6.2f us\n", time_us(bigs));
-    printf("the five launches back to back                 %6.2f us\n", time_us([&] { count(nwaves, nb, pn, P); prefix(); scatter(); waves(); bigs(); }));
+    printf("the four launches back to back                 %6.2f us\n", time_us([&] { count(nwaves, nb, pn, P); prefix(); scatter(); waves(); }));
     (void)lds_count;
     return 0;
 }
