@@ -54,9 +54,34 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float depth = 0.f;
     int radius = 0;
 
+    // The kernel is one generation of waves: its time is the number of DEPENDENT memory round trips a thread makes.  What a
+    // thread needs is therefore requested up front (position, shape, opacity: 44 bytes, also for the few Gaussians the near
+    // plane culls), the 192 bytes of SH coefficients right behind the near-plane test -- in flight while the covariance is
+    // projected -- instead of one trip each behind the tests that decide whether they are needed (four trips).
     const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    float c6in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float3 sc_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6in[k] = cov3D_precomp[6 * i + k];
+    } else {
+        sc_in = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
+        q_in = reinterpret_cast<const float4*>(rotations)[i];
+    }
+    const float opacity_in = opacities[i];
     const float3 pv = xform4x3(p, V);
     bool ok = pv.z > 0.2f;  // near cull (p_view.z <= 0.2 is culled)
+    const bool sh_early = ok && !colors_precomp && M == 16 && ((uintptr_t)shs & 15u) == 0;
+    float shl[48];
+    if (sh_early) {
+        const float4* g4 = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float4 v = g4[k];
+            shl[4 * k] = v.x; shl[4 * k + 1] = v.y; shl[4 * k + 2] = v.z; shl[4 * k + 3] = v.w;
+        }
+    }
     if (ok) {
         const float4 ph = xform4x4(p, PV);
         const float pw = 1.0f / (ph.w + 0.0000001f);
@@ -64,11 +89,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         float c6[6];
         if (cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * i + k];
+            for (int k = 0; k < 6; k++) c6[k] = c6in[k];
         } else {
-            const float3 sc = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
-            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
-            cov3d_from_scale_rot(sc, scale_modifier, q, c6);
+            cov3d_from_scale_rot(sc_in, scale_modifier, q_in, c6);
         }
         float cov[3], Mx[2][3], tcl[3], tt2[2];
         cov2d(p, focal_x, focal_y, tanfovx, tanfovy, c6, V, cov, Mx, tcl, tt2);
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     // bin into the bounding box of the alpha >= 1/255 region only (GsFwdArgs.tile_rect = 1); the
                     // Gaussian stays "visible" (radii, colour, depth) exactly as with the square
                     float hx, hy;
-                    if (snug_half_widths(opacities[i], cov[0], cov[2], det, &hx, &hy)) {
+                    if (snug_half_widths(opacity_in, cov[0], cov[2], det, &hx, &hy)) {
                         minx = max(minx, (int)((px - hx) / TILE));
                         miny = max(miny, (int)((py - hy) / TILE));
                         maxx = min(maxx, (int)((px + hx) / TILE) + 1);
@@ -113,6 +136,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 float3 col;
                 if (colors_precomp) {
                     col = make_float3(colors_precomp[3 * i], colors_precomp[3 * i + 1], colors_precomp[3 * i + 2]);
+                } else if (sh_early) {
+                    col = sh_to_rgb(deg, p, make_float3(campos[0], campos[1], campos[2]), shl, &cl);
                 } else {
                     col = load_and_eval_sh(deg, M, p, make_float3(campos[0], campos[1], campos[2]), shs, i, &cl);
                 }
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 radius = r;
                 tt = (uint32_t)(w * h);
                 r0 = make_float4(px, py, cA, cB);
-                r1 = make_float4(cC, opacities[i], col.x, col.y);
+                r1 = make_float4(cC, opacity_in, col.x, col.y);
                 r2x = col.z;
                 rmin_bits = (uint32_t)minx | ((uint32_t)miny << 16);
                 rsize_bits = (uint32_t)w | ((uint32_t)h << 16);
