@@ -141,24 +141,36 @@ __device__ __forceinline__ int segment_of(unsigned long long before, unsigned lo
     const unsigned long long hi = __umul64hi(before, scale), lo = before * scale;
     return (int)min((unsigned long long)(nseg - 1), (hi << 32) | (lo >> 32));
 }
-__device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
-                                               unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;
+// (in two parts: the loads are requested where the kernel starts, the bounds derived where it needs them -- the writing
+// pass has its own prologue of loads in between, and a round trip to the L2 is most of what either costs)
+struct SegLoads { uint32_t w[4]; uint32_t w_prev; unsigned long long mine; };
+__device__ __forceinline__ SegLoads segment_loads(const uint32_t* __restrict__ chunk_pairs, int P) {
+    const int tid = threadIdx.x, nthreads = (int)blockDim.x;
     const int nchunks = (P + 255) / 256;
     const int per = (nchunks + nthreads - 1) / nthreads;  // consecutive chunks per thread
     const int c0 = tid * per;
     // the thread's chunk sums, four loads in flight (kept when they are all it has: P <= 1024 * its workgroup's threads),
     // and the one in front of them
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    const uint32_t w_prev = (c0 > 0 && c0 <= nchunks) ? chunk_pairs[c0 - 1] : 0u;
-    unsigned long long mine = 0;
+    SegLoads L;
+    L.w[0] = L.w[1] = L.w[2] = L.w[3] = 0u;
+    L.w_prev = (c0 > 0 && c0 <= nchunks) ? chunk_pairs[c0 - 1] : 0u;
+    L.mine = 0;
     for (int k0 = 0; k0 < per; k0 += 4) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
+        for (int k = 0; k < 4; k++) L.w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) mine += w[k];
+        for (int k = 0; k < 4; k++) L.mine += L.w[k];
     }
+    return L;
+}
+__device__ __forceinline__ void segment_bounds(SegLoads L, const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
+                                               unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;
+    const int nchunks = (P + 255) / 256;
+    const int per = (nchunks + nthreads - 1) / nthreads;
+    const int c0 = tid * per;
+    const unsigned long long mine = L.mine;
     const unsigned long long x = wave_scan_incl(mine);
     int* bounds = reinterpret_cast<int*>(scratch + 16);
     if (lane == 63) scratch[wid] = x;
@@ -170,14 +182,16 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
         woff += wv < wid ? c : 0ull;
         total += c;
     }
-    const unsigned long long scale = ((unsigned long long)nseg << 32) / total;  // (total >= SEG_RANK_W: P > 0)
+    // scale = nseg 2^32 / total as the double quotient (the same value in every workgroup of both passes; a 64-bit integer
+    // division is ~150 dependent instructions: 0.7 us of every workgroup's life)
+    const unsigned long long scale = (unsigned long long)((double)nseg * 4294967296.0 / (double)total);  // (total >= SEG_RANK_W: P > 0)
     unsigned long long before = woff + x - mine;  // work before this thread's first chunk
     int prev_seg = -1;  // segment of the chunk before this thread's first one
-    if (c0 > 0 && c0 <= nchunks) prev_seg = segment_of(before - ((unsigned long long)w_prev + SEG_RANK_W), scale, nseg);
+    if (c0 > 0 && c0 <= nchunks) prev_seg = segment_of(before - ((unsigned long long)L.w_prev + SEG_RANK_W), scale, nseg);
     for (int k0 = 0; k0 < per; k0 += 4) {
         if (per > 4) {  // (workgroup-uniform)
 #pragma unroll
-            for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
+            for (int k = 0; k < 4; k++) L.w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -187,7 +201,7 @@ __device__ __forceinline__ void segment_bounds(const uint32_t* __restrict__ chun
                 if (sgc >= sg && prev_seg < sg) bounds[0] = c;           // first chunk of segment sg or later
                 if (sgc >= sg + 1 && prev_seg < sg + 1) bounds[1] = c;   // first chunk past segment sg
                 prev_seg = sgc;
-                before += w[k];
+                before += L.w[k];
             }
         }
     }
@@ -214,9 +228,10 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
     const int y0b = band * band_rows, y1b = min(gy, y0b + band_rows);
     const int rows = y1b - y0b, ld = gx + 1;
     const int cells = (rows + 1) * ld;
+    const SegLoads sl = segment_loads(chunk_pairs, P);
     for (int k = tid; k < cells; k += TC_THREADS) grid[k] = 0;
     int r0, r1;
-    segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);  // (its barriers also cover the zeroing above)
+    segment_bounds(sl, chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);  // (its barriers also cover the zeroing above)
     for (int rb = r0 + tid; rb < r1; rb += 4 * TC_THREADS) {
         uint4 e[4];  // four loads in flight per thread
 #pragma unroll
@@ -403,6 +418,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 // first loads are issued together, the filter takes two trips of 4096 ranks with one barrier pair each, and a bitmap
 // batch needs two barriers.
 #define BM_LD 33          // words per tile in the bitmap (32 + 1: tile-major rows fall into different banks)
+#ifndef TW_STOP_AFTER
+#define TW_STOP_AFTER 99  // tools/tw_parts.hip builds the kernel with parts left out: 1 prologue, 2 + segment bounds, 3 + filter
+#endif
 __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist,
                                                                  const uint32_t* __restrict__ chunk_pairs, int P, int gx,
                                                                  int gy, int nbx, int nblocks, int nseg, int ntiles,
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const SegLoads sl = segment_loads(chunk_pairs, P);  // (used behind the prologue: in flight beside its loads)
     const int b = ((int)blockIdx.x - 1) % nblocks, sg = ((int)blockIdx.x - 1) / nblocks;
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
@@ -486,10 +505,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         }
         __syncthreads();  // (sb_scratch is segment_bounds' from here on)
     }
+    if (TW_STOP_AFTER <= 1) return;  // (tools/tw_parts.hip: where the kernel's time goes; 99 in the product)
     if (!fits || !point_list) return;  // (workgroup-uniform) the host sees the count and runs the phase again, larger state
     for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
     int r0, r1;
-    segment_bounds(chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
+    segment_bounds(sl, chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
     uint4 e[TBK_LPL];
     auto load_trip = [&](const int rb) {
 #pragma unroll
@@ -498,6 +518,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             e[k] = r < r1 ? ranklist[r] : make_uint4(0, 0, 0, 0);  // (tiles touched = 0: never a match)
         }
     };
+    if (TW_STOP_AFTER <= 2) return;
     load_trip(r0);
     if (tid < TB_TILES) dst[tid] = my_dst;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         const bool last = rb >= r1;
         while (count >= TBK_BATCH || (last && count > 0)) {
             const int n = min(count, TBK_BATCH);
-            process_batch(n);
+            if (TW_STOP_AFTER > 3) process_batch(n);
             const int rem = count - n;  // < TBK_CHUNK: at most TBK_LPL elements per thread move to the front
             uint32_t cid[TBK_LPL];
             unsigned short crc[TBK_LPL];
