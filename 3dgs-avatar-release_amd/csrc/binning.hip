@@ -127,111 +127,32 @@ __device__ __forceinline__ bool block_hit(const uint4 e, int bx0, int by0, int b
     return hit;
 }
 
-// The ranking is cut into `nseg` SEGMENTS of about equal work, not of equal length: the nearest Gaussians come first
-// and cover hundreds of tiles each, so equal-length segments leave the workgroups of the first segments with ten times
-// the pairs of the others (they then ARE the kernel's run time).  Work of a chunk of 256 ranks = its pairs + SEG_RANK_W
-// (the cost of filtering 256 ranks, in pairs); chunk c belongs to segment floor(nseg * work before c / total work), so the
-// segments are contiguous runs of chunks (possibly empty).  Every workgroup derives the run of its segment itself: one
-// load of the chunk sums and a 1024-wide scan.  Returns the rank range [*r0, *r1) of segment sg.
-#define SEG_RANK_W 4096u
-// (the segment of a chunk with `before` work in front of it: floor(before * scale / 2^32), scale = floor(nseg * 2^32 / total)
-// -- non-decreasing in `before`, below nseg because before < total, and a multiply per chunk instead of a 64-bit division;
-// the counting and the writing pass cut the ranking with this same function, which is all that matters)
-__device__ __forceinline__ int segment_of(unsigned long long before, unsigned long long scale, int nseg) {
-    const unsigned long long hi = __umul64hi(before, scale), lo = before * scale;
-    return (int)min((unsigned long long)(nseg - 1), (hi << 32) | (lo >> 32));
-}
-// (in two parts: the loads are requested where the kernel starts, the bounds derived where it needs them -- the writing
-// pass has its own prologue of loads in between, and a round trip to the L2 is most of what either costs)
-struct SegLoads { uint32_t w[4]; uint32_t w_prev; unsigned long long mine; };
-__device__ __forceinline__ SegLoads segment_loads(const uint32_t* __restrict__ chunk_pairs, int P) {
-    const int tid = threadIdx.x, nthreads = (int)blockDim.x;
-    const int nchunks = (P + 255) / 256;
-    const int per = (nchunks + nthreads - 1) / nthreads;  // consecutive chunks per thread
-    const int c0 = tid * per;
-    // the thread's chunk sums, four loads in flight (kept when they are all it has: P <= 1024 * its workgroup's threads),
-    // and the one in front of them
-    SegLoads L;
-    L.w[0] = L.w[1] = L.w[2] = L.w[3] = 0u;
-    L.w_prev = (c0 > 0 && c0 <= nchunks) ? chunk_pairs[c0 - 1] : 0u;
-    L.mine = 0;
-    for (int k0 = 0; k0 < per; k0 += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) L.w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; k++) L.mine += L.w[k];
-    }
-    return L;
-}
-__device__ __forceinline__ void segment_bounds(SegLoads L, const uint32_t* __restrict__ chunk_pairs, int P, int nseg, int sg,
-                                               unsigned long long* scratch /* LDS: 20 words */, int* r0, int* r1) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;
-    const int nchunks = (P + 255) / 256;
-    const int per = (nchunks + nthreads - 1) / nthreads;
-    const int c0 = tid * per;
-    const unsigned long long mine = L.mine;
-    const unsigned long long x = wave_scan_incl(mine);
-    int* bounds = reinterpret_cast<int*>(scratch + 16);
-    if (lane == 63) scratch[wid] = x;
-    if (tid == 0) { bounds[0] = nchunks; bounds[1] = nchunks; }
-    __syncthreads();
-    unsigned long long woff = 0, total = 0;
-    for (int wv = 0; wv < nwaves; wv++) {
-        const unsigned long long c = scratch[wv];
-        woff += wv < wid ? c : 0ull;
-        total += c;
-    }
-    // scale = nseg 2^32 / total as the double quotient (the same value in every workgroup of both passes; a 64-bit integer
-    // division is ~150 dependent instructions: 0.7 us of every workgroup's life)
-    const unsigned long long scale = (unsigned long long)((double)nseg * 4294967296.0 / (double)total);  // (total >= SEG_RANK_W: P > 0)
-    unsigned long long before = woff + x - mine;  // work before this thread's first chunk
-    int prev_seg = -1;  // segment of the chunk before this thread's first one
-    if (c0 > 0 && c0 <= nchunks) prev_seg = segment_of(before - ((unsigned long long)L.w_prev + SEG_RANK_W), scale, nseg);
-    for (int k0 = 0; k0 < per; k0 += 4) {
-        if (per > 4) {  // (workgroup-uniform)
-#pragma unroll
-            for (int k = 0; k < 4; k++) L.w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? chunk_pairs[c0 + k0 + k] + SEG_RANK_W : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c = c0 + k0 + k;
-            if (k0 + k < per && c < nchunks) {
-                const int sgc = segment_of(before, scale, nseg);
-                if (sgc >= sg && prev_seg < sg) bounds[0] = c;           // first chunk of segment sg or later
-                if (sgc >= sg + 1 && prev_seg < sg + 1) bounds[1] = c;   // first chunk past segment sg
-                prev_seg = sgc;
-                before += L.w[k];
-            }
-        }
-    }
-    __syncthreads();
-    *r0 = min(P, bounds[0] * 256);
-    *r1 = min(P, bounds[1] * 256);
-    __syncthreads();
-}
-
 // ---- counting pass.  How many Gaussians of rank segment g cover tile t?  A rectangle adds +1 / -1 at its four
 // corners of a (rows + 1) x (gx + 1) grid in LDS and a 2-D prefix sum turns the corners into coverage counts: four LDS
 // atomics per Gaussian instead of one per pair.  Workgroup (band of tile rows, segment); the band is the whole grid
 // unless the grid is too large for LDS.
 #define TC_CELLS 12288  // grid cells (4-byte) a workgroup holds
 __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __restrict__ ranklist,
-                                                                 const uint32_t* __restrict__ chunk_pairs, int P, int gx,
+                                                                 const uint32_t* __restrict__ chunk_pairs,
+                                                                 uint32_t* __restrict__ seg_start, int P, int gx,
                                                                  int gy, int band_rows, int nbands, int nseg, int ntiles,
                                                                  uint32_t* __restrict__ seg_cnt,
                                                                  uint32_t* __restrict__ tile_tot) {
     __shared__ int grid[TC_CELLS];
-    __shared__ unsigned long long sb_scratch[20];
+    __shared__ unsigned long long sb_scratch[16];
+    __shared__ uint32_t s_seg[TB_MAX_SEG + 2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int band = (int)blockIdx.x % nbands, sg = (int)blockIdx.x / nbands;
     const int y0b = band * band_rows, y1b = min(gy, y0b + band_rows);
     const int rows = y1b - y0b, ld = gx + 1;
     const int cells = (rows + 1) * ld;
-    const SegLoads sl = segment_loads(chunk_pairs, P);
     for (int k = tid; k < cells; k += TC_THREADS) grid[k] = 0;
-    int r0, r1;
-    segment_bounds(sl, chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);  // (its barriers also cover the zeroing above)
+    // the rank segments (common.h: segment_starts), derived in LDS by every workgroup of this launch, stored by the first
+    // for the writing pass
+    segment_starts(chunk_pairs, P, nseg, s_seg, sb_scratch);
+    __syncthreads();  // (also covers the zeroing above)
+    const int r0 = min(P, (int)s_seg[sg] * 256), r1 = min(P, (int)s_seg[sg + 1] * 256);  // this segment's ranks
+    if (blockIdx.x == 0 && tid <= nseg) seg_start[tid] = s_seg[tid];
     for (int rb = r0 + tid; rb < r1; rb += 4 * TC_THREADS) {
         uint4 e[4];  // four loads in flight per thread
 #pragma unroll
@@ -419,10 +340,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 // batch needs two barriers.
 #define BM_LD 33          // words per tile in the bitmap (32 + 1: tile-major rows fall into different banks)
 #ifndef TW_STOP_AFTER
-#define TW_STOP_AFTER 99  // tools/tw_parts.hip builds the kernel with parts left out: 1 prologue, 2 + segment bounds, 3 + filter
+#define TW_STOP_AFTER 99  // tools/tw_parts.hip builds the kernel with parts left out: 1 prologue, 2 + bitmap clear, 3 + filter
 #endif
 __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist,
-                                                                 const uint32_t* __restrict__ chunk_pairs, int P, int gx,
+                                                                 const uint32_t* __restrict__ seg_start, int P, int gx,
                                                                  int gy, int nbx, int nblocks, int nseg, int ntiles,
                                                                  const uint32_t* __restrict__ seg_cnt,
                                                                  const uint32_t* __restrict__ tile_tot,
@@ -444,8 +365,8 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const SegLoads sl = segment_loads(chunk_pairs, P);  // (used behind the prologue: in flight beside its loads)
     const int b = ((int)blockIdx.x - 1) % nblocks, sg = ((int)blockIdx.x - 1) / nblocks;
+    const int r0 = min(P, (int)seg_start[sg] * 256), r1 = min(P, (int)seg_start[sg + 1] * 256);  // this segment's ranks
     const int bx0 = (b % nbx) * TB_W, by0 = (b / nbx) * TB_H;
     const int bx1 = min(gx, bx0 + TB_W), by1 = min(gy, by0 + TB_H);
     const unsigned long long frame_pairs = *pc.dev;
@@ -488,7 +409,7 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
         }
         part = wave_sum(part);
         rowsum = wave_sum(rowsum);
-        uint32_t* s_part = reinterpret_cast<uint32_t*>(sb_scratch);  // 16 partial sums + 4 row sums (free until segment_bounds)
+        uint32_t* s_part = reinterpret_cast<uint32_t*>(sb_scratch);  // 16 partial sums + 4 row sums
         if (lane == 0) {
             s_part[wid] = part;
             if (wid < TB_H) s_part[16 + wid] = rowsum;
@@ -503,13 +424,11 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
             if (sg == 0 && tile_ok) ranges[t] = fits ? make_uint2(first, first + tot) : make_uint2(0u, 0u);
             my_dst = first + pre;
         }
-        __syncthreads();  // (sb_scratch is segment_bounds' from here on)
+        __syncthreads();
     }
     if (TW_STOP_AFTER <= 1) return;  // (tools/tw_parts.hip: where the kernel's time goes; 99 in the product)
     if (!fits || !point_list) return;  // (workgroup-uniform) the host sees the count and runs the phase again, larger state
     for (int k = tid; k < TB_TILES * BM_LD; k += TBK_THREADS) bitmap[k] = 0u;
-    int r0, r1;
-    segment_bounds(sl, chunk_pairs, P, nseg, sg, sb_scratch, &r0, &r1);
     uint4 e[TBK_LPL];
     auto load_trip = [&](const int rb) {
 #pragma unroll
@@ -664,7 +583,7 @@ int launch_tile_order(const uint32_t* ranges, const uint32_t* keys, int mode, in
 // whose workgroups derive the tile ranges and their list slots from the counts themselves and whose first workgroup
 // orders the tiles for the render launch.  `totals_zeroed`: tc.tile_tot .. (tc.zero_bytes) were cleared by an earlier
 // kernel of this frame (the preprocess kernel); otherwise they are cleared here.
-int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
+int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32_t* seg_start, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
                       uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, bool totals_zeroed, int debug,
                       hipStream_t s) {
     uint32_t* seg_cnt = tc.seg_cnt;
@@ -682,14 +601,14 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P,
         if (band_rows > gy) band_rows = gy;
         const int nbands = (gy + band_rows - 1) / band_rows;
         StageScope sc_("tile_count", s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, s, ranklist, chunk_pairs, P,
+        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, s, ranklist, chunk_pairs, seg_start, P,
                            gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt, tc.tile_tot);
         GS_LAUNCH_CHECK("tile_count", debug, s);
     }
     {
         StageScope sc_("tile_write", s);
         hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, s, ranklist,
-                           chunk_pairs, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
+                           seg_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
                            reinterpret_cast<uint2*>(ranges), order, pc.cap > 0 ? point_list : nullptr, pc, ll);
         GS_LAUNCH_CHECK("tile_write", debug, s);
     }

@@ -218,7 +218,8 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     int rc;
     if (a->P > 0) {
         point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
-        rc = launch_tile_lists((const uint4*)(g + L.ranklist), (const uint32_t*)(g + L.chunk_pairs), a->P, I.gx, I.gy,
+        rc = launch_tile_lists((const uint4*)(g + L.ranklist), (const uint32_t*)(g + L.chunk_pairs), (uint32_t*)(g + L.seg_start),
+                               a->P, I.gx, I.gy,
                                TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), I.tile_zero_bytes},
                                ranges, (uint32_t*)(im + I.order),
                                cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc,

@@ -38,9 +38,10 @@ static inline int ds_buckets(int P) {
     return nb < 256 ? 256 : (nb > 4096 ? 4096 : nb);
 }
 
+#define TB_MAX_SEG 64  // rank segments of the tile-list launches, at most (binning.hip)
 struct GeomLayout {
     size_t rec, depths, tiles, clamped, key0, key1, val0, val1, ranklist, chunk_pairs, wsum, wkmin, wkmax, hist, count,
-        ds_tmp, ds_tmp2, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, total;
+        ds_tmp, ds_tmp2, ds_cnt, ds_pre, ds_tot, ds_loc, ds_grp, ds_range, seg_start, total;
     int nblk_sort, nwaves, ds_nb, ds_blocks;
 };
 static inline GeomLayout geom_layout(int P) {
@@ -76,6 +77,7 @@ static inline GeomLayout geom_layout(int P) {
     L.ds_loc = take((size_t)(L.ds_nb + 1) * 4);
     L.ds_grp = take((size_t)((L.ds_nb + 1 + 63) / 64) * 4);
     L.ds_range = take(16);
+    L.seg_start = take((size_t)(TB_MAX_SEG + 2) * 4);              // first chunk of 256 ranks of every rank segment (binning.hip)
     L.total = o;
     return L;
 }
@@ -107,7 +109,6 @@ static inline BinLayout bin_layout(int64_t D) {
 #define TB_H 4   // 1, 2 or 4 (the clipped rectangle's rows are packed in 2 bits)
 #endif
 #define TB_TILES (TB_W * TB_H)
-#define TB_MAX_SEG 64
 struct BinGrid { int nbx, nby, nblocks, nseg_max; };
 static inline BinGrid bin_grid(int gx, int gy) {
     BinGrid G;
@@ -262,6 +263,73 @@ __device__ __forceinline__ float wave_sum(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
+// ---- rank segments (binning.hip).  The ranking is cut into `nseg` SEGMENTS of about equal work, not of equal length: the
+// nearest Gaussians come first and cover hundreds of tiles each, so equal-length segments leave the workgroups of the
+// first segments with ten times the pairs of the others (they then ARE the kernel's run time).  Work of a chunk of 256
+// ranks = its pairs + SEG_RANK_W (the cost of filtering 256 ranks, in pairs); chunk c belongs to segment
+// floor(before * scale / 2^32), scale = nseg 2^32 / total work -- non-decreasing in the work `before` in front of the
+// chunk, so the segments are contiguous runs of chunks (possibly empty).  segment_starts stores the first chunk of every
+// segment: seg_start[0 .. nseg], seg_start[nseg] = the number of chunks.  Every workgroup of the COUNTING pass derives
+// them in LDS (one load of the chunk sums, a workgroup-wide scan) and its first one also stores them; the workgroups of
+// the WRITING pass -- sixteen times as many, each spending 5 us on the same derivation until round 3 -- read two words.
+// What matters for the lists is only that both passes cut the ranking at the same places.
+#define SEG_RANK_W 4096u
+__device__ __forceinline__ int segment_of(unsigned long long before, unsigned long long scale, int nseg) {
+    const unsigned long long hi = __umul64hi(before, scale), lo = before * scale;
+    return (int)min((unsigned long long)(nseg - 1), (hi << 32) | (lo >> 32));
+}
+__device__ __forceinline__ void segment_starts(const uint32_t* __restrict__ chunk_pairs, int P, int nseg, uint32_t* seg_start /* LDS */,
+                                               unsigned long long* scratch /* LDS: 16 words */) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;
+    const int nchunks = (P + 255) / 256;
+    const int per = (nchunks + nthreads - 1) / nthreads;  // consecutive chunks per thread
+    const int c0 = tid * per;
+    // (all of a thread's loads at once: four in flight, kept when they are all it has -- P <= 1024 * the workgroup's threads)
+    auto work = [&](int c) { return chunk_pairs[c] + SEG_RANK_W; };
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    const uint32_t w_prev = (c0 > 0 && c0 < nchunks) ? work(c0 - 1) : 0u;
+    unsigned long long mine = 0;
+    for (int k0 = 0; k0 < per; k0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? work(c0 + k0 + k) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) mine += w[k];
+    }
+    const unsigned long long x = wave_scan_incl(mine);
+    __syncthreads();  // (scratch may be in use until here)
+    if (lane == 63) scratch[wid] = x;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+    for (int wv = 0; wv < nwaves; wv++) {
+        const unsigned long long c = scratch[wv];
+        woff += wv < wid ? c : 0ull;
+        total += c;
+    }
+    const unsigned long long scale = (unsigned long long)((double)nseg * 4294967296.0 / (double)total);  // (total >= SEG_RANK_W: P > 0)
+    unsigned long long before = woff + x - mine;  // work before this thread's first chunk
+    int prev_seg = -1;                            // segment of the chunk before it
+    if (c0 > 0 && c0 < nchunks) prev_seg = segment_of(before - w_prev, scale, nseg);
+    for (int k0 = 0; k0 < per; k0 += 4) {
+        if (per > 4) {  // (workgroup-uniform; otherwise the four words are still there)
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = (k0 + k < per && c0 + k0 + k < nchunks) ? work(c0 + k0 + k) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = c0 + k0 + k;
+            if (k0 + k < per && c < nchunks) {
+                const int sgc = segment_of(before, scale, nseg);
+                for (int sg = prev_seg + 1; sg <= sgc; sg++) seg_start[sg] = (uint32_t)c;  // first chunk of segment sg (or of the next non-empty one)
+                prev_seg = sgc;
+                before += w[k];
+                if (c == nchunks - 1)
+                    for (int sg = prev_seg + 1; sg <= nseg; sg++) seg_start[sg] = (uint32_t)nchunks;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void zero_job(const ZeroJob z) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;
 }
@@ -352,7 +420,7 @@ struct TileCounts { uint32_t *seg_cnt, *tile_tot; size_t zero_bytes; };
 // what the tile-order launch of the forward also does: mark the tiles whose list is long against the frame's total in
 // the launch order (bit 31; render_fwd.hip) and report how many there are and the longest list (GsFwdArgs.frame_stats)
 struct LongLists { int mark; long long* stats; };
-int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
+int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32_t* seg_start, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
                       uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, bool totals_zeroed, int debug,
                       hipStream_t s);
 

@@ -1,6 +1,6 @@
 // Where the time of the tile-list launches goes: the product kernels (csrc/binning.hip, included as they are) alone on the
 // chip on a synthetic ranking shaped like config 3's (200k Gaussians in random depth order, rectangles of ~17 tiles on a
-// 64 x 64 tile grid).  Built once per stop point (-DTW_STOP_AFTER=1 | 2 | 3 | 99: tile_write_kernel with its later parts
+// 64 x 64 tile grid).  Built once per stop point (-DTW_STOP_AFTER=1 | 3 | 99: tile_write_kernel with its later parts
 // left out); tools/tw_parts.sh builds and runs all four.
 #include "../3dgs-avatar-release_amd/csrc/binning.hip"
 #include <stdio.h>
@@ -43,10 +43,10 @@ int main() {
     }
     const BinGrid G = bin_grid(gx, gy);
     const int nseg = bin_segments(G, P);
-    uint4* d_rank; uint32_t *d_chunk, *d_seg, *d_tot, *d_ranges, *d_order, *d_list; unsigned long long* d_count;
+    uint4* d_rank; uint32_t *d_chunk, *d_seg, *d_tot, *d_ranges, *d_order, *d_list, *d_start; unsigned long long* d_count;
     (void)hipMalloc(&d_rank, (size_t)P * 16); (void)hipMalloc(&d_chunk, chunk.size() * 4); (void)hipMalloc(&d_seg, (size_t)ntiles * 4 * G.nseg_max);
     (void)hipMalloc(&d_tot, (size_t)ntiles * 4 + 256); (void)hipMalloc(&d_ranges, (size_t)ntiles * 8); (void)hipMalloc(&d_order, (size_t)ntiles * 4);
-    (void)hipMalloc(&d_list, (size_t)D * 4 + 1024); (void)hipMalloc(&d_count, 64);
+    (void)hipMalloc(&d_list, (size_t)D * 4 + 1024); (void)hipMalloc(&d_count, 64); (void)hipMalloc(&d_start, (TB_MAX_SEG + 2) * 4);
     (void)hipMemcpy(d_rank, rank.data(), (size_t)P * 16, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_chunk, chunk.data(), chunk.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_count, &D, 8, hipMemcpyHostToDevice);
@@ -56,8 +56,8 @@ int main() {
     if (band_rows > gy) band_rows = gy;
     const int nbands = (gy + band_rows - 1) / band_rows;
     auto zero = [&] { (void)hipMemsetAsync(d_tot, 0, (size_t)ntiles * 4, 0); };
-    auto count = [&] { hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, 0, d_rank, d_chunk, P, gx, gy, band_rows, nbands, nseg, ntiles, d_seg, d_tot); };
-    auto write = [&] { hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, 0, d_rank, d_chunk, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, d_seg, d_tot, reinterpret_cast<uint2*>(d_ranges), d_order, d_list, pc, ll); };
+    auto count = [&] { hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, 0, d_rank, d_chunk, d_start, P, gx, gy, band_rows, nbands, nseg, ntiles, d_seg, d_tot); };
+    auto write = [&] { hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, 0, d_rank, d_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, d_seg, d_tot, reinterpret_cast<uint2*>(d_ranges), d_order, d_list, pc, ll); };
     zero(); count(); (void)hipDeviceSynchronize();
     if (TW_STOP_AFTER == 99) {
         printf("D = %llu pairs, %d segments x %d blocks\n", D, nseg, G.nblocks);
