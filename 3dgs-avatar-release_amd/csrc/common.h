@@ -273,7 +273,9 @@ __device__ __forceinline__ float wave_sum(float x) {
 // them in LDS (one load of the chunk sums, a workgroup-wide scan) and its first one also stores them; the workgroups of
 // the WRITING pass -- sixteen times as many, each spending 5 us on the same derivation until round 3 -- read two words.
 // What matters for the lists is only that both passes cut the ranking at the same places.
+#ifndef SEG_RANK_W
 #define SEG_RANK_W 4096u
+#endif
 __device__ __forceinline__ int segment_of(unsigned long long before, unsigned long long scale, int nseg) {
     const unsigned long long hi = __umul64hi(before, scale), lo = before * scale;
     return (int)min((unsigned long long)(nseg - 1), (hi << 32) | (lo >> 32));

@@ -32,7 +32,10 @@ int main() {
     srand(3);
     unsigned long long D = 0;
     for (int r = 0; r < P; r++) {
-        const int w = 2 + rand() % 6, h = 2 + rand() % 6;
+        // nearer Gaussians (low ranks) are larger on screen, as in the benchmark scene: depth 2 .. 4 over the ranking
+        const float depth = 2.0f + 2.0f * (float)r / (float)P, base = 4.2f * 3.0f / depth;
+        const int w = (int)(base + (rand() % 3 - 1) + 0.5f) < 1 ? 1 : (int)(base + (rand() % 3 - 1) + 0.5f);
+        const int h = (int)(base + (rand() % 3 - 1) + 0.5f) < 1 ? 1 : (int)(base + (rand() % 3 - 1) + 0.5f);
         int x0 = rand() % (gx + w) - w, y0 = rand() % (gy + h) - h;
         int x1 = x0 + w, y1 = y0 + h;
         x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > gx ? gx : x1; y1 = y1 > gy ? gy : y1;
