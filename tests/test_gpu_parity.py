@@ -1924,3 +1924,37 @@ def test_gradient_row_marks_set_by_the_forward_and_by_a_repeated_backward():
     assert torch.equal(color, color0)
     for a, b in zip(first, plain):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_opacity", [False, True])
+def test_call_under_no_grad_takes_the_path_without_an_autograd_node_and_gives_the_same_bits(with_opacity):
+    """Under torch.no_grad() (the reference's render loop, render.py:51-62) rasterize_gaussians calls the forward directly
+    instead of through autograd.Function.apply: same image, radii and opacity image bit for bit, no graph attached -- also
+    when the inputs require gradients, as the reference's parameters do while it renders for evaluation."""
+    import diff_gaussian_rasterization as dgr
+    dev = torch.device("cuda:0")
+    n, W, H = 6000, 200, 150
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=5, scale_mul=1.3)
+    kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+    means3D = cloud.xyz.to(dev).requires_grad_(True)
+    means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+    opac = cloud.opacity.to(dev).requires_grad_(True)
+    rast = dgr.GaussianRasterizer(_settings(cam, cloud, (0.3, 0.1, 0.2), dev))
+    extra = {"with_opacity": True} if with_opacity else {}
+    out_grad = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw, **extra)
+    assert out_grad[0].requires_grad and out_grad[0].grad_fn is not None
+    dgr.release_shared_geometry()
+    calls = []
+    real_apply = dgr._RasterizeGaussians.apply
+    try:
+        dgr._RasterizeGaussians.apply = lambda *a: (calls.append(1), real_apply(*a))[1]
+        with torch.no_grad():
+            out = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw, **extra)
+    finally:
+        dgr._RasterizeGaussians.apply = real_apply
+    assert not calls  # (no autograd.Function.apply on this path)
+    assert len(out) == len(out_grad) == (3 if with_opacity else 2)
+    for a, b in zip(out, out_grad):
+        assert not a.requires_grad and a.grad_fn is None
+        assert torch.equal(a, b.detach())
