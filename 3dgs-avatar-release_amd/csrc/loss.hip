@@ -137,14 +137,25 @@ __global__ __launch_bounds__(SS_NT) void ssim_fwd_kernel(int H, int W, const flo
     const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;  // ty in 0..7: rows 4 ty .. 4 ty + 3
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    // halo tiles: 42 rows of 42, a row per trip of 64 threads (no integer division)
-    for (int r = tid >> 6; r < SS_H; r += SS_NT / 64) {
+    // halo tiles: 42 rows of 42, a row per trip of 64 threads (no integer division).  All of a thread's 22 loads are
+    // requested before the first is stored to LDS (as a plain loop the compiler waits for every load in turn: 22 dependent
+    // round trips in front of the arithmetic of every workgroup)
+    {
+        constexpr int TRIPS = (SS_H + SS_NT / 64 - 1) / (SS_NT / 64);
         const int c = tid & 63;
-        if (c < SS_H) {
+        float v1[TRIPS], v2[TRIPS];
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const int r = (tid >> 6) + u * (SS_NT / 64);
             const int y = y0 + r - SS_R, x = x0 + c - SS_R;
-            const bool in = y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
-            t1[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
-            t2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
+            const bool in = r < SS_H && c < SS_H && y >= 0 && y < H && x >= 0 && x < W;  // zero padding (conv2d padding = 5)
+            v1[u] = in ? img1[plane + (size_t)y * W + x] : 0.f;
+            v2[u] = in ? img2[plane + (size_t)y * W + x] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const int r = (tid >> 6) + u * (SS_NT / 64);
+            if (r < SS_H && c < SS_H) { t1[r][c] = v1[u]; t2[r][c] = v2[u]; }
         }
     }
     __syncthreads();
@@ -259,15 +270,24 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, const flo
     const int tid = threadIdx.x, tx = tid % SS_T, ty = tid / SS_T;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int r = tid >> 6; r < SS_H; r += SS_NT / 64) {
+    {  // (all 33 loads of a thread requested before the first LDS store: see ssim_fwd_kernel)
+        constexpr int TRIPS = (SS_H + SS_NT / 64 - 1) / (SS_NT / 64);
         const int c = tid & 63;
-        if (c < SS_H) {
+        float v0[TRIPS], v1[TRIPS], v2[TRIPS];
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const int r = (tid >> 6) + u * (SS_NT / 64);
             const int y = y0 + r - SS_R, x = x0 + c - SS_R;
-            const bool in = y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
+            const bool in = r < SS_H && c < SS_H && y >= 0 && y < H && x >= 0 && x < W;  // windows centred outside the image do not exist
             const size_t o = plane + (size_t)y * W + x;
-            t[0][r][c] = in ? dm_dmu1[o] : 0.f;
-            t[1][r][c] = in ? dm_ds1[o] : 0.f;
-            t[2][r][c] = in ? dm_ds12[o] : 0.f;
+            v0[u] = in ? dm_dmu1[o] : 0.f;
+            v1[u] = in ? dm_ds1[o] : 0.f;
+            v2[u] = in ? dm_ds12[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const int r = (tid >> 6) + u * (SS_NT / 64);
+            if (r < SS_H && c < SS_H) { t[0][r][c] = v0[u]; t[1][r][c] = v1[u]; t[2][r][c] = v2[u]; }
         }
     }
     __syncthreads();
