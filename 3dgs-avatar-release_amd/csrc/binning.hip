@@ -215,7 +215,11 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
 __device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
                                               int t) {
     if (mode == 2) return keys[t];
-    return mode ? (keys[4 * t] + keys[4 * t + 1] + keys[4 * t + 2] + keys[4 * t + 3]) : (ranges[t].y - ranges[t].x);
+    if (mode) {  // (one 16-byte load: the four quadrant counts of a tile are adjacent and the array is 256-byte aligned)
+        const uint4 q = reinterpret_cast<const uint4*>(keys)[t];
+        return (q.x + q.y) + (q.z + q.w);
+    }
+    return ranges[t].y - ranges[t].x;
 }
 // One workgroup of 1024 threads.  HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the
 // inputs are loaded once, all loads in flight together (ntiles <= 32 * 1024); otherwise the phases re-read them.
@@ -231,10 +235,14 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
     uint32_t mx = 0;
     if (HELD) {
 #pragma unroll
-        for (int i = 0; i < PER; i++) {
+        for (int i = 0; i < PER; i++) {  // (the loads alone first: all of them in flight before the first is looked at)
             if (i * 1024 >= ntiles) break;  // workgroup-uniform
             const int t = i * 1024 + tid;
             held[i] = t < ntiles ? tile_work(ranges, keys, mode, t) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
             mx = max(mx, held[i]);
         }
     } else {

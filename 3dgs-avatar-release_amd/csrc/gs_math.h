@@ -179,13 +179,22 @@ __device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float*
         int r = (int)threadIdx.x / rf4, c = (int)threadIdx.x - r * rf4;
         const int dr = (int)blockDim.x / rf4, dc = (int)blockDim.x - dr * rf4;
         const float4* g4 = reinterpret_cast<const float4*>(g);
-        for (int e = threadIdx.x; e < total4; e += blockDim.x) {
-            const float4 v = g4[e];
-            float* d = lds + r * ld + 4 * c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            r += dr;
-            c += dc;
-            if (c >= rf4) { c -= rf4; r++; }
+        // four loads in flight per thread and trip (as a plain loop every load is waited for before its LDS stores: twelve
+        // dependent round trips for a full SH tile)
+        for (int e0 = threadIdx.x; e0 < total4; e0 += 4 * (int)blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = e0 + u * (int)blockDim.x < total4 ? g4[e0 + u * (int)blockDim.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e0 + u * (int)blockDim.x < total4) {
+                    float* d = lds + r * ld + 4 * c;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+                r += dr;
+                c += dc;
+                if (c >= rf4) { c -= rf4; r++; }
+            }
         }
         return;
     }
