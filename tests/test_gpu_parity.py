@@ -1958,3 +1958,30 @@ def test_call_under_no_grad_takes_the_path_without_an_autograd_node_and_gives_th
     for a, b in zip(out, out_grad):
         assert not a.requires_grad and a.grad_fn is None
         assert torch.equal(a, b.detach())
+
+
+@pytest.mark.gpu
+def test_depth_ranking_of_a_million_equal_depths():
+    """1.2 M Gaussians at ONE view-space depth: one bucket of the depth ranking holds them all, is cut into 1024 sub-buckets
+    by sampling (depth_sort.hip: ds_giant_bucket) and every sub-bucket (~1200 composites) is still too large for a wave,
+    so the whole workgroup sorts it: the last of the ranking's paths.  Equal keys rank in ascending index order -- the
+    stable order -- so the ranking of the Gaussians that touch a tile must be their indices in ascending order."""
+    from gsplat_mi355 import debug
+    from gsplat_mi355.camera import orbit_camera
+    from gsplat_mi355.scenes import GaussianCloud
+    dev = torch.device("cuda:0")
+    n, W, H = 1_200_000, 256, 256
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.empty(n, 3).uniform_(-0.9, 0.9, generator=g)
+    xyz[:, 2] = 0.125  # every view-space depth is exactly 3.125
+    cloud = GaussianCloud(xyz, torch.full((n, 3), 0.004), torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(n, 1),
+                                  torch.full((n, 1), 0.5), torch.rand(n, 1, 3, generator=g), 0)
+    cam = orbit_camera(0, W, H)
+    st = debug.forward_state(_settings(cam, cloud, (0.0, 0.0, 0.0), dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    tt = st["geom"]["tiles_touched"]
+    order = st["geom"]["sorted_idx"].astype(np.int64)
+    nvis = int((tt > 0).sum())
+    assert nvis > 1_000_000 and len(np.unique(st["geom"]["depths"][tt > 0])) == 1
+    assert np.array_equal(order[:nvis], np.nonzero(tt > 0)[0])
+    assert np.array_equal(np.sort(order[nvis:]), np.nonzero(tt == 0)[0])
