@@ -174,9 +174,8 @@ __device__ __forceinline__ void switch_entry(EntryQ& e, uint32_t lds_addr, unsig
 // obtains with a second rasterizer call (gaussian_renderer/__init__.py:132-142) -- and dL_dopa is the gradient of
 // that channel: one more term in (c . g) and in Gtot, nothing else changes.
 // MODE 0: one image; 1 (OPA): + the opacity channel; 2 (SECOND): + a second image of the same geometry; 3 (SONES): + a
-// second image whose colours are all (1, 1, 1) -- the reference's opacity pass (gaussian_renderer/__init__.py:132-142):
-// its colour term is the same for every entry, (c2 . h) = h0 + h1 + h2 of the pixel, so the loop is MODE 1's (one add, no
-// second colours gathered, staged or read) with MODE 2's set-up.  Both 2 and 3 are launched for a second image; each
+// second image whose colours are all (1, 1, 1) -- the reference's opacity pass (gaussian_renderer/__init__.py:132-142).
+// Modes 1 and 3 run MODE 0's loop: an image of colours one enters through the pixel's starting value alone (see the set-up).  Both 2 and 3 are launched for a second image; each
 // leaves at once unless the second image's `all_ones` word says it is its case (the host does not know).
 #ifndef BWD_MIN_WAVES
 #define BWD_MIN_WAVES 1
@@ -207,8 +206,8 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
     // different quarters of the banks (at 32 words apart rings 0 / 2 and 1 / 3 collide):  g0, g1, g2, x, y, lim
     // ... stored as PAIRS (one ds_read_b64 per pair: 2 LDS cycles for 8 bytes per lane where two ds_read_b32 take 4 -- with
     // the entry switch done by LDS reads the kernel sits close to the LDS's cycle budget): (g0, g1) (g2, x) (y, lim)
-    // [+ (g4, -) / (h0, h1) (h2, -)]
-    constexpr int NP2 = (OPA || SONES) ? 4 : (SECOND ? 5 : 3);
+    // [+ (h0, h1) (h2, -)]
+    constexpr int NP2 = SECOND ? 5 : 3;
     __shared__ float2 pix[NP2][4 * RING_STRIDE];
     // the converted entries of a chunk, staged by ring 0 at a round start for the switch reads of the NEXT round
     __shared__ bwd_f4 ent[ENT_SLOTS][RING][3];
@@ -247,14 +246,20 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
             const uint32_t nc = ncon_c[pid];
             c1.z = __uint_as_float((nc > (uint32_t)k0 ? nc - (uint32_t)k0 : 0u) + (uint32_t)j);
+            // An image whose colours are all ONE -- the opacity channel o = (1 - Tf) + Tf bg, or a second render with
+            // colours (1, 1, 1) -- needs nothing in the loop: its (c . g) is the same g4 for every entry, and with
+            // sum_{j <= i} alpha_j T_j = 1 - T_{i+1} its share of dL/dalpha_i = T_i g4 - Rem_i / (1 - alpha_i) collapses to
+            // g4 (1 - o) / (1 - alpha_i), the same constant over (1 - alpha_i) at every entry: it is SUBTRACTED FROM Gtot
+            // once, here, and the recurrence carries it (also from a checkpoint: no term there).  (Until round 3: one more
+            // pixel constant read and added per step, 265 against 245 us at config 3.)
             if (OPA) {
                 const float Tf = final_T[pid];
-                c1.w = dL_dopa[pid];
-                c0.w += ((1.0f - Tf) + Tf * bg[0]) * c1.w;  // the opacity channel's share of Gtot
+                c0.w -= dL_dopa[pid] * (Tf * (1.0f - bg[0]));  // g4 (1 - o),  1 - o = Tf (1 - bg)
             }
             if (SECOND || SONES) {
                 h = make_float3(second.dL_dpix[pid], second.dL_dpix[HW + pid], second.dL_dpix[2 * HW + pid]);
-                c0.w += second.out_color[pid] * h.x + second.out_color[HW + pid] * h.y + second.out_color[2 * HW + pid] * h.z;
+                if (SECOND) c0.w += second.out_color[pid] * h.x + second.out_color[HW + pid] * h.y + second.out_color[2 * HW + pid] * h.z;
+                else c0.w -= (1.0f - second.out_color[pid]) * h.x + (1.0f - second.out_color[HW + pid]) * h.y + (1.0f - second.out_color[2 * HW + pid]) * h.z;
             }
             if (chunk > 0) {
                 // the forward's state before entry k0: T, and the colour composited so far (the opacity channel's is 1 - T)
@@ -262,8 +267,7 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
                 const float4 ck = ckpt[ci];
                 T0 = ck.x;
                 c0.w -= ck.y * g0 + ck.z * g1 + ck.w * g2;
-                if (OPA) c0.w -= (1.0f - ck.x) * c1.w;
-                if (SECOND || SONES) {
+                if (SECOND) {
                     const float4 ck2 = second.ckpt[ci];  // (the second render's own checkpoints: same T, its colours)
                     c0.w -= ck2.y * h.x + ck2.z * h.y + ck2.w * h.z;
                 }
@@ -273,8 +277,6 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
         pix[0][slot] = pix[0][slot + RING] = make_float2(c0.x, c0.y);
         pix[1][slot] = pix[1][slot + RING] = make_float2(c0.z, c1.x);
         pix[2][slot] = pix[2][slot + RING] = make_float2(c1.y, c1.z);
-        if (OPA) pix[3][slot] = pix[3][slot + RING] = make_float2(c1.w, 0.f);
-        if (SONES) pix[3][slot] = pix[3][slot + RING] = make_float2(h.x + h.y + h.z, 0.f);
         if (SECOND) {
             pix[3][slot] = pix[3][slot + RING] = make_float2(h.x, h.y);
             pix[4][slot] = pix[4][slot + RING] = make_float2(h.z, 0.f);
@@ -383,7 +385,6 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             const float3 g = make_float3(pc[0].x, pc[0].y, pc[1].x);  // dL/dpixel of the pixel at this lane
             const float pxf = pc[1].y, pyf = pc[2].x;
             const uint32_t lim = __float_as_uint(pc[2].y);
-            const float g4 = (OPA || SONES) ? pc[3].x : 0.f;
             const float h0 = SECOND ? pc[3].x : 0.f, h1 = SECOND ? pc[3].y : 0.f, h2 = SECOND ? pc[NP2 - 1].x : 0.f;
             // next step's pixel constants, fetched now
             pidx += 1u;
@@ -403,7 +404,6 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             const float Gv = valid ? G : 0.f;
             const float wgt = alpha * T;
             float cg = cur.q1.z * g.x + cur.q1.w * g.y + cur.q2.x * g.z;
-            if constexpr (OPA || SONES) cg += g4;
             if constexpr (SECOND) cg += cur.q2.y * h0 + cur.q2.z * h1 + cur.q2.w * h2;
             Rem = __builtin_fmaf(-cg, wgt, Rem);
             const float one_m = 1.f - alpha;
