@@ -1985,3 +1985,38 @@ def test_depth_ranking_of_a_million_equal_depths():
     assert nvis > 1_000_000 and len(np.unique(st["geom"]["depths"][tt > 0])) == 1
     assert np.array_equal(order[:nvis], np.nonzero(tt > 0)[0])
     assert np.array_equal(np.sort(order[nvis:]), np.nonzero(tt == 0)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["depth_sort", "xcd_map", "nt_stores", "bwd_order", "fwd_marks"])
+def test_library_switches_without_an_effect_on_the_results(switch):
+    """gs_tuning switches documented as "without effect on the results" (include/gsplat_mi355.h): the LSD radix sort in
+    place of the bucket sort of the depth ranking, the tile -> XCD mapping of the render launches, streaming stores for
+    the row marks, the backward's own tile order, the forward's side job -- image, radii and every gradient bit for bit
+    the default's (the per-pixel and per-Gaussian sums do not depend on which wave runs when)."""
+    import diff_gaussian_rasterization as dgr
+    from gsplat_mi355 import _lib
+    dev = torch.device("cuda:0")
+    n, W, H = 9000, 272, 208
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=23, scale_mul=1.2)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run():
+        kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, "sh", "scale_rot", dev).items()}
+        means3D = cloud.xyz.to(dev).requires_grad_(True)
+        means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+        opac = cloud.opacity.to(dev).requires_grad_(True)
+        color, radii = dgr.GaussianRasterizer(_settings(cam, cloud, (0.2, 0.3, 0.1), dev))(means3D=means3D, means2D=means2D,
+                                                                                            opacities=opac, **kw)
+        (color * gimg).sum().backward()
+        return [color.detach().clone(), radii.clone()] + [t.grad.clone() for t in (means3D, means2D, opac, kw["shs"], kw["scales"],
+                                                                                   kw["rotations"])]
+
+    ref = run()
+    _lib.tuning(switch, 0)
+    try:
+        alt = run()
+    finally:
+        _lib.tuning(switch, 1)
+    for a, b in zip(ref, alt):
+        assert torch.equal(a, b)
