@@ -127,3 +127,27 @@ def test_neighbouring_entry_points_validate_on_the_host(lib):
     assert L.gs_build_covariance(0, None, 1.0, None, 0, None, None) == 0
     assert L.gs_adam_step(0, None, 0.9, 0.999, 1e-15, 1, None) == 0
     assert L.gs_densify_stats(0, None, None, None, None, None, None) == 0
+
+
+def test_inference_context_offers_what_the_forward_uses_of_an_autograd_context():
+    """Under no_grad the wrapper calls the forward with a plain object in place of the autograd context
+    (diff_gaussian_rasterization._InferenceCtx).  Every METHOD the forward path calls on `ctx` must exist there -- attributes
+    it merely assigns are fine on any object -- and the entry points of the path must keep the argument count
+    needs_input_grad is sized for."""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "3dgs-avatar-release_amd"))
+    import diff_gaussian_rasterization as dgr
+    src = inspect.getsource(dgr._RasterizeGaussians._forward) + inspect.getsource(dgr._RasterizeGaussians._finish) + \
+        inspect.getsource(dgr._RasterizeGaussians.forward)
+    called = set(re.findall(r"\bctx\.([a-z_]+)\(", src))
+    read = set(re.findall(r"\bctx\.([a-z_]+)\b(?!\s*=[^=])", src)) - called
+    ictx = dgr._InferenceCtx()
+    for name in called:
+        assert callable(getattr(ictx, name, None)), name
+    assigned = set(re.findall(r"\bctx\.([a-z_]+)\s*=[^=]", src))
+    for name in read - assigned:
+        assert hasattr(ictx, name), name
+    n_inputs = len(inspect.signature(dgr._RasterizeGaussians.forward).parameters) - 1  # (ctx)
+    assert len(ictx.needs_input_grad) == n_inputs
+    assert not any(ictx.needs_input_grad)
