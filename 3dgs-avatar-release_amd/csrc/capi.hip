@@ -341,10 +341,19 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
         // SAME long_lists as to the first render, so that both image states have the same layout)
         not_ones = (gs_tune_get(GS_TUNE_ONES_FAST) && gs_tune_get(GS_TUNE_SHARED_QLIST) && a->colors_precomp && D > 0)
                        ? (unsigned long long*)(const_cast<char*>(gs) + L.count) + 2 : nullptr;
+        // ... and, when the colours may turn out to be all ones, the launch's other workgroups write the image that is
+        // right in that case (1 - T of the first render, with its records): the render launch below then leaves at once
+        const int chunks_ = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
+        const SecondOnes so{(const float*)(is + I.final_T), (const uint32_t*)(is + I.n_contrib), (const uint32_t*)(is + I.ncon_c),
+                            (const uint32_t*)(is + I.tile_nmax), (const float4*)(is + I.ckpt), (const uint32_t*)(is + I.ck_start),
+                            out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), (uint32_t*)(im + I.ncon_c),
+                            (uint32_t*)(im + I.tile_nmax), chunks_ > 1 ? (float4*)(im + I.ckpt) : nullptr,
+                            chunks_ > 1 ? (uint32_t*)(im + I.ck_start) : nullptr, a->bg, a->W, a->H, I.gx, ntiles,
+                            chunks_ > 1 ? chunks_ : 1};
         rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
-                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones, (uint32_t*)(im + I.all_ones),
+                            (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones,
                             CopyJob{(const uint32_t*)(is + I.ranges), (uint32_t*)(im + I.ranges), ntiles * 2},
-                            CopyJob{(const uint32_t*)(is + I.order), (uint32_t*)(im + I.order), ntiles}, s);
+                            CopyJob{(const uint32_t*)(is + I.order), (uint32_t*)(im + I.order), ntiles}, not_ones ? &so : nullptr, s);
         if (rc != GS_OK) return rc;
     } else {
         // (no Gaussians: no recolouring launch to ride in) the new image state's own copy of the tile ranges and launch order
@@ -367,18 +376,12 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
+    ql.all_ones = (uint32_t*)(im + I.all_ones);  // (set by the render launch: 1 iff it left the speculative image alone)
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, (const uint32_t*)(im + I.ranges),
                                (const uint32_t*)(im + I.order), a->bg, a->W, a->H, out_color, (float*)(im + I.final_T),
                                (uint32_t*)(im + I.n_contrib), ql, s); }
     if (rc != GS_OK) return rc;
-    if (ql.not_ones) {  // ... or, colours all ones, the image from the first render's transmittance
-        StageScope sc_("second_ones", s);
-        rc = launch_second_ones(a->bg, a->W, a->H, ql, (const float*)(is + I.final_T), (const uint32_t*)(is + I.ncon_c),
-                                (const float4*)(is + I.ckpt), (const uint32_t*)(is + I.ck_start), out_color,
-                                (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), (uint32_t*)(im + I.all_ones), s);
-        if (rc != GS_OK) return rc;
-    }
     if (a->debug) {
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) { gs_set_error((int)e, "render_forward"); return GS_E_HIP; }

@@ -388,9 +388,53 @@ int launch_depth_sort(const uint32_t* keys, const uint32_t* wave_kmin, const uin
                       DepthSortState st, PairNumbering pn, RankOut ro, int debug, hipStream_t s);
 // word ranges some kernel copies on the side (grid-stride), saving copy launches
 struct CopyJob { const uint32_t* src; uint32_t* dst; int words; };
+// A second render of the same geometry whose colours are all (1, 1, 1) -- the reference's opacity pass
+// (gaussian_renderer/__init__.py:132-142) -- needs no compositing: every channel is sum_k alpha_k T_k = 1 - T_final, plus
+// T_final bg, and the first render's per-pixel / per-quadrant records hold for it as they are (same geometry: same T, same
+// contributors), checkpoints included (colour composited before a chunk = 1 - T there).  Whether the colours ARE all ones
+// is only known when the recolouring launch has looked at them, so that launch's other workgroups write this image
+// SPECULATIVELY (second_ones_body; per-pixel part in memory order, a wave per quadrant for the records) and the render
+// launch behind it either leaves everything as it is (all ones) or composites over it.  (Until round 3: a launch of its own
+// behind the render launch.)
+struct SecondOnes {
+    const float* src_final_T; const uint32_t* src_n_contrib; const uint32_t* src_ncon_c; const uint32_t* src_qcount;
+    const float4* src_ckpt; const uint32_t* src_ck_start;
+    float* out_color; float* final_T; uint32_t* n_contrib; uint32_t* ncon_c; uint32_t* qcount; float4* ckpt; uint32_t* ck_start;
+    const float* bg; int W, H, gx, ntiles, chunks;
+};
+__device__ __forceinline__ void second_ones_body(const SecondOnes& A, const int block, const int pixel_blocks) {
+    if (block < pixel_blocks) {
+        // one pixel per thread, 256 consecutive pixels per workgroup (a wave per quadrant touches eight 32-byte runs per
+        // access: 1.4 TB/s)
+        const size_t HW = (size_t)A.H * A.W, pid = (size_t)block * 256 + threadIdx.x;
+        if (pid < HW) {
+            const float Tf = A.src_final_T[pid];
+            A.final_T[pid] = Tf;
+            A.n_contrib[pid] = A.src_n_contrib[pid];
+            A.ncon_c[pid] = A.src_ncon_c[pid];
+            A.out_color[pid] = (1.0f - Tf) + Tf * A.bg[0];
+            A.out_color[HW + pid] = (1.0f - Tf) + Tf * A.bg[1];
+            A.out_color[2 * HW + pid] = (1.0f - Tf) + Tf * A.bg[2];
+        }
+        return;
+    }
+    const int quad = (block - pixel_blocks) * 4 + ((int)threadIdx.x >> 6), tile = quad >> 2, lane = threadIdx.x & 63;
+    if (tile >= A.ntiles) return;
+    if (lane == 0) A.qcount[quad] = A.src_qcount[quad];
+    if (A.chunks > 1) {
+        if (lane < A.chunks) A.ck_start[(size_t)quad * A.chunks + lane] = A.src_ck_start[(size_t)quad * A.chunks + lane];
+        for (int c = 1; c < A.chunks; c++) {
+            if (A.src_ck_start[(size_t)quad * A.chunks + c] == 0xFFFFFFFFu) break;  // (in order: none behind it either)
+            const size_t ci = ((size_t)quad * (size_t)(A.chunks - 1) + (size_t)(c - 1)) * 64 + lane;
+            const float Tc = A.src_ckpt[ci].x;
+            A.ckpt[ci] = make_float4(Tc, 1.0f - Tc, 1.0f - Tc, 1.0f - Tc);
+        }
+    }
+}
+// `ones`: not null = the launch's other workgroups write the speculative all-ones image
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
-                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, uint32_t* all_ones_init,
-                   CopyJob c0, CopyJob c1, hipStream_t s);
+                   uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, CopyJob c0, CopyJob c1,
+                   const SecondOnes* ones, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
@@ -489,6 +533,7 @@ struct QuadLists {
     uint4* marks = nullptr;
     size_t mark_quads = 0;
     uint32_t* marks_flag = nullptr;
+    uint32_t* all_ones = nullptr;  // (a second render) the image state's "this image is 1 - T of the first render" word
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
@@ -508,9 +553,6 @@ int launch_render_backward(const float* rec, const uint32_t* ranges, const uint3
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
                            hipStream_t s);
-int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
-                       const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
-                       uint32_t* n_contrib, uint32_t* all_ones, hipStream_t s);
 // opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,

@@ -45,6 +45,9 @@ struct FwdArgs {
     uint4* __restrict__ marks;
     size_t mark_quads;
     uint32_t* __restrict__ marks_flag;
+    // (a second render) the image state's word that says "this image IS 1 - T of the first render": this launch -- the one
+    // that decides between compositing and leaving the speculative 1 - T image (common.h: second_ones_body) -- sets it
+    uint32_t* __restrict__ all_ones;
 };
 __device__ __forceinline__ void forward_side_fill(const FwdArgs& A) {
     if (!A.marks) {  // not this launch's job; a state word it owns must not keep what an earlier use of the memory left there
@@ -270,6 +273,7 @@ template <bool FQ>
 __global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
     __shared__ float4 srec[66 * 3];
     int slot, q;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.all_ones) *A.all_ones = (A.not_ones && *A.not_ones == 0ull) ? 1u : 0u;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot < A.ntiles && !(FQ && A.not_ones && *A.not_ones == 0ull))
         render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(FWD4_BATCH) void render_fwd_small_kernel(const FwdA
     __shared__ float4 srec[(FWD4_BATCH + 12) * 3];
     __shared__ uint32_t s_cnt[4], s_flag[4], s_lastk[4];
     int slot, q;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.all_ones) *A.all_ones = (A.not_ones && *A.not_ones == 0ull) ? 1u : 0u;
     render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
     if (slot < A.ntiles && !(FQ && A.not_ones && *A.not_ones == 0ull)) {
         const uint32_t ov = A.order[slot];  // heaviest tiles first; bit 31: all four waves (tile_order_kernel)
@@ -561,7 +566,7 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
-                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag};
+                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag, ql.all_ones};
     const dim3 grid(render_grid_blocks(gx * gy, xmap));
     const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
@@ -586,63 +591,6 @@ __global__ __launch_bounds__(256) void opacity_image_kernel(const float* __restr
     if (i >= n) return;
     const float Tf = final_T[i];
     out[i] = (1.0f - Tf) + Tf * bg[0];
-}
-
-// A second render of the same geometry whose colours are all (1, 1, 1) -- the reference's opacity pass
-// (gaussian_renderer/__init__.py:132-142) -- needs no compositing: every channel is sum_k alpha_k T_k = 1 - T_final, plus
-// T_final bg.  One wave per quadrant writes the image and takes the first render's per-pixel / per-quadrant records over
-// (same geometry: same T, same contributors), checkpoints included (colour composited before a chunk = 1 - T there).
-// Leaves at once unless *not_ones == 0 (recolor_kernel); render_fwd*<true> leave at once if it IS 0.
-struct SecondOnes {
-    const float* src_final_T; const uint32_t* src_n_contrib; const uint32_t* src_ncon_c; const uint32_t* src_qcount;
-    const float4* src_ckpt; const uint32_t* src_ck_start;
-    float* out_color; float* final_T; uint32_t* n_contrib; uint32_t* ncon_c; uint32_t* qcount; float4* ckpt; uint32_t* ck_start;
-    const float* bg; const unsigned long long* not_ones; int W, H, gx, ntiles, chunks; uint32_t* all_ones;
-};
-__global__ __launch_bounds__(256) void second_ones_kernel(const SecondOnes A, const int pixel_blocks) {
-    if (*A.not_ones != 0ull) return;
-    if ((int)blockIdx.x < pixel_blocks) {
-        // the per-pixel part, in memory order: one pixel per thread, 256 consecutive pixels per workgroup (a wave per
-        // quadrant touches eight 32-byte runs per access: 1.4 TB/s)
-        const size_t HW = (size_t)A.H * A.W, pid = (size_t)blockIdx.x * 256 + threadIdx.x;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && A.all_ones) *A.all_ones = 1u;  // this image IS 1 - T: the one-pass backward may rely on it
-        if (pid < HW) {
-            const float Tf = A.src_final_T[pid];
-            A.final_T[pid] = Tf;
-            A.n_contrib[pid] = A.src_n_contrib[pid];
-            A.ncon_c[pid] = A.src_ncon_c[pid];
-            A.out_color[pid] = (1.0f - Tf) + Tf * A.bg[0];
-            A.out_color[HW + pid] = (1.0f - Tf) + Tf * A.bg[1];
-            A.out_color[2 * HW + pid] = (1.0f - Tf) + Tf * A.bg[2];
-        }
-        return;
-    }
-    // the per-quadrant records: a wave per quadrant
-    const int quad = ((int)blockIdx.x - pixel_blocks) * 4 + (threadIdx.x >> 6), tile = quad >> 2, lane = threadIdx.x & 63;
-    if (tile >= A.ntiles) return;
-    if (lane == 0) A.qcount[quad] = A.src_qcount[quad];
-    if (A.chunks > 1) {
-        if (lane < A.chunks) A.ck_start[(size_t)quad * A.chunks + lane] = A.src_ck_start[(size_t)quad * A.chunks + lane];
-        for (int c = 1; c < A.chunks; c++) {
-            if (A.src_ck_start[(size_t)quad * A.chunks + c] == 0xFFFFFFFFu) break;  // (in order: none behind it either)
-            const size_t ci = ((size_t)quad * (size_t)(A.chunks - 1) + (size_t)(c - 1)) * 64 + lane;
-            const float Tc = A.src_ckpt[ci].x;
-            A.ckpt[ci] = make_float4(Tc, 1.0f - Tc, 1.0f - Tc, 1.0f - Tc);
-        }
-    }
-}
-
-int launch_second_ones(const float* bg, int W, int H, const QuadLists& ql, const float* src_final_T, const uint32_t* src_ncon_c,
-                       const float4* src_ckpt, const uint32_t* src_ck_start, float* out_color, float* final_T,
-                       uint32_t* n_contrib, uint32_t* all_ones, hipStream_t s) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    const int chunks = ql.ckpt ? ql.chunks : 1;
-    const SecondOnes A{src_final_T, ql.src_n_contrib, src_ncon_c, ql.src_qcount, src_ckpt, src_ck_start, out_color, final_T,
-                       n_contrib, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start, bg, ql.not_ones, W, H, gx, gx * gy, chunks, all_ones};
-    const int pixel_blocks = (int)(((size_t)W * H + 255) / 256);
-    hipLaunchKernelGGL(second_ones_kernel, dim3((unsigned)(pixel_blocks + gx * gy)), dim3(256), 0, s, A, pixel_blocks);
-    GS_LAUNCH_CHECK("second_ones", 0, s);
-    return GS_OK;
 }
 
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s) {
