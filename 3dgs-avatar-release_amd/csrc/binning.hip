@@ -599,8 +599,8 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32
     const int nseg = bin_segments(G, P);  // segments of about equal work (segment_bounds)
     const int ntiles = gx * gy;
     if (!totals_zeroed) {
-        hipError_t e = hipMemsetAsync(tc.tile_tot, 0, tc.zero_bytes, s);
-        if (e != hipSuccess) { gs_set_error((int)e, "tile_totals.memset"); return GS_E_HIP; }
+        const int zrc = gs_zero_async(tc.tile_tot, tc.zero_bytes, "tile_totals.zero", s);  // (a kernel node: graph-capturable)
+        if (zrc != GS_OK) return zrc;
     }
     {
         // counting pass: bands of tile rows that fit the LDS grid (the whole tile grid up to ~110 x 110 tiles)

@@ -54,6 +54,7 @@ struct ProfState {
 #include <atomic>
 static ProfState g_prof;
 static std::mutex g_prof_mu;
+static bool profiling_on() { return g_prof.on; }
 void gs_prof_begin(const char* stage, hipStream_t s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -88,6 +89,44 @@ static int validate(const GsFwdArgs* a) {
     // quaternions are read (and their gradients written) as float4
     if (a->rotations && ((uintptr_t)a->rotations & 15u)) return GS_E_BAD_ARG;
     if ((a->W + TILE - 1) / TILE > 0xFFFF || (a->H + TILE - 1) / TILE > 0xFFFF) return GS_E_TOO_LARGE;
+    return GS_OK;
+}
+
+// ---- stream capture (hipGraph) -----------------------------------------------------------------
+// Round 3 recorded a GPU memory fault ("write access to a read-only page") on the first replay of a captured
+// gs_forward_preprocess + gs_forward_render.  What those two calls put into the graph besides kernel nodes: a memset
+// node (the per-tile totals), a device-to-host memcpy node into the caller's pinned count word, and a kernel that
+// STORES into pinned host memory (GsFwdArgs.frame_stats).  None of that is needed under capture: the library now asks
+// hipStreamIsCapturing at every entry point, enqueues KERNEL NODES ONLY on a capturing stream (zero_words_kernel instead
+// of memset nodes), and answers GS_E_CAPTURE -- before enqueuing anything -- to every call that would need more.
+static bool stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const hipError_t e = hipStreamIsCapturing((hipStream_t)stream, &st);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        // (asking about the legacy stream while another stream captures in global mode is itself a capture error)
+        return e == hipErrorStreamCaptureImplicit || e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureInvalidated;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+// capture-safe entry points: refuse debug mode (it synchronises) and the stage timer (event nodes) under capture
+#define GS_CAPTURE_OK_IF(stream, cond)                                           \
+    do {                                                                         \
+        if (stream_is_capturing(stream) && (!(cond) || profiling_on())) return GS_E_CAPTURE; \
+    } while (0)
+#define GS_NO_CAPTURE(stream) GS_CAPTURE_OK_IF(stream, false)
+
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t words) {
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < words; k += (size_t)gridDim.x * blockDim.x) p[k] = 0u;
+}
+// `bytes` (a multiple of 4) of zeros as a kernel node (a memset node in eager mode would do: one code path for both)
+int gs_zero_async(void* ptr, size_t bytes, const char* stage, hipStream_t s) {
+    const size_t words = bytes / 4;
+    if (words == 0) return GS_OK;
+    const size_t blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, (uint32_t*)ptr, words);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gs_set_error((int)e, stage); return GS_E_HIP; }
     return GS_OK;
 }
 
@@ -134,8 +173,8 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     char* g = (char*)geom;
     unsigned long long* count = (unsigned long long*)(g + L.count);
     if (a->P == 0) {
-        hipError_t e = hipMemsetAsync(count, 0, 24, s);
-        if (e != hipSuccess) { gs_set_error((int)e, "count.memset"); return GS_E_HIP; }
+        rc = gs_zero_async(count, 24, "count.zero", s);
+        if (rc != GS_OK) return rc;
     } else {
         uint32_t* k0 = (uint32_t*)(g + L.key0);
         uint32_t* k1 = (uint32_t*)(g + L.key1);
@@ -190,6 +229,7 @@ static int forward_phase1(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 
 int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* img, size_t img_bytes,
                           int32_t* radii, int64_t* count_host_pinned, void* stream) {
+    GS_CAPTURE_OK_IF(stream, a && !a->debug && count_host_pinned == nullptr);
     return forward_phase1(a, geom, geom_bytes, img, img_bytes, radii, count_host_pinned, nullptr, stream);
 }
 
@@ -227,8 +267,8 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
                                totals_zeroed, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
-        hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s);
-        if (e != hipSuccess) { gs_set_error((int)e, "ranges.memset"); return GS_E_HIP; }
+        rc = gs_zero_async(ranges, (size_t)ntiles * 8, "ranges.zero", s);
+        if (rc != GS_OK) return rc;
         StageScope sc_("ranges_order", s);
         rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), pc, FillJob{nullptr, 0},
                                LongLists{0, nullptr}, a->debug, s);
@@ -260,6 +300,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 
 int gs_forward_render(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                       void* img, size_t img_bytes, int64_t D, float* out_color, void* stream) {
+    GS_CAPTURE_OK_IF(stream, a && !a->debug && a->frame_stats == nullptr);
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     return forward_phase2(a, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, stream, false);
@@ -276,6 +317,7 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
                void* img, size_t img_bytes, int32_t* radii, int64_t* count_host_pinned, float* out_color,
                int64_t* num_rendered, void* stream) {
     if (!count_host_pinned || !num_rendered || capacity < 0) return GS_E_BAD_ARG;
+    GS_NO_CAPTURE(stream);  // (the host waits for the pair count: gs_forward_preprocess + gs_forward_render are the capturable form)
     volatile int64_t* word = count_host_pinned;
     const int64_t pending = -1;
     static std::atomic<bool> poll_works{true};  // cleared for the process if a device write to the word is ever not seen
@@ -320,6 +362,7 @@ int gs_forward(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning,
 int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_src, void* geom, size_t geom_bytes,
                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int64_t D, float* out_color,
                       void* stream) {
+    GS_CAPTURE_OK_IF(stream, a && !a->debug && a->P > 0);
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom_src || !img_src || !geom || !img || !out_color || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
@@ -390,6 +433,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
 }
 
 int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, float* opacity, void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!img || !opacity) return GS_E_BAD_ARG;
@@ -402,6 +446,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
                          size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
                          const float* dL_dpix, const float* dL_dopacity_img, void* scratch, size_t scratch_bytes,
                          const GsGrads* gr, void* stream, const GsSecondImage* second = nullptr) {
+    GS_CAPTURE_OK_IF(stream, a && !a->debug);
     int rc = validate(a);
     if (rc != GS_OK) return rc;
     if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch)) return GS_E_BAD_ARG;
@@ -495,6 +540,7 @@ int gs_backward_with_second(const GsFwdArgs* a, const int32_t* radii, const void
 
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     (void)projmatrix;
     if (P < 0 || !viewmatrix || (P > 0 && (!means3D || !present))) return GS_E_BAD_ARG;
     if (P == 0) return GS_OK;
@@ -507,6 +553,7 @@ int knn_workspace_bytes(int32_t P, size_t* out) {
     return GS_OK;
 }
 int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, size_t workspace_bytes, void* stream) {
+    GS_NO_CAPTURE(stream);  // (the sorts clear their tables with memset nodes: untested under replay)
     if (P < 0 || (P > 0 && (!points || !mean_d2 || !workspace))) return GS_E_BAD_ARG;
     if (P == 0) return GS_OK;
     return launch_knn(P, points, mean_d2, workspace, workspace_bytes, (hipStream_t)stream);
@@ -514,6 +561,7 @@ int knn_dist2(int32_t P, const float* points, float* mean_d2, void* workspace, s
 
 int gs_build_covariance(int32_t N, const float* scaling, float scaling_modifier, const float* rotation, int32_t rotation_is_matrix,
                         float* cov6, void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (N < 0 || (N > 0 && (!scaling || !rotation || !cov6))) return GS_E_BAD_ARG;
     if (!rotation_is_matrix && ((uintptr_t)rotation & 15u)) return GS_E_BAD_ARG;  // quaternions are read as float4
     if (N == 0) return GS_OK;
@@ -522,6 +570,7 @@ int gs_build_covariance(int32_t N, const float* scaling, float scaling_modifier,
 int gs_build_covariance_backward(int32_t N, const float* scaling, float scaling_modifier, const float* rotation,
                                  int32_t rotation_is_matrix, const float* dL_dcov6, float* dL_dscaling, float* dL_drotation,
                                  void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (N < 0 || (N > 0 && (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation))) return GS_E_BAD_ARG;
     if (!rotation_is_matrix && (((uintptr_t)rotation | (uintptr_t)dL_drotation) & 15u)) return GS_E_BAD_ARG;
     if (N == 0) return GS_OK;
@@ -530,6 +579,7 @@ int gs_build_covariance_backward(int32_t N, const float* scaling, float scaling_
 }
 int gs_sh2rgb(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
               const float* fwd_rotation, const float* view_noise_host, float* colors, uint8_t* clamped, void* stream) {
+    GS_CAPTURE_OK_IF(stream, view_noise_host == nullptr);  // (a host matrix would be baked into the graph)
     if (N < 0 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) return GS_E_BAD_ARG;
     if (N > 0 && (!shs || !xyz || !campos || !colors || !clamped)) return GS_E_BAD_ARG;
     if (N == 0) return GS_OK;
@@ -538,6 +588,7 @@ int gs_sh2rgb(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const f
 int gs_sh2rgb_backward(int32_t N, int32_t sh_degree, int32_t M, const float* shs, const float* xyz, const float* campos,
                        const float* fwd_rotation, const float* view_noise_host, const uint8_t* clamped,
                        const float* dL_dcolors, float* dL_dshs, float* dL_dxyz, void* stream) {
+    GS_CAPTURE_OK_IF(stream, view_noise_host == nullptr);
     if (N < 0 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) return GS_E_BAD_ARG;
     if (N > 0 && (!shs || !xyz || !campos || !clamped || !dL_dcolors || !dL_dshs || !dL_dxyz)) return GS_E_BAD_ARG;
     if (N == 0) return GS_OK;
@@ -552,6 +603,7 @@ int gs_l1_loss_workspace_bytes(int64_t n, size_t* out) {
 }
 int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace, size_t workspace_bytes,
                void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (n <= 0 || !x || !y || !loss || !dL_dx || !workspace) return GS_E_BAD_ARG;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)dL_dx) & 15u) return GS_E_BAD_ARG;  // float4 accesses
     if (workspace_bytes < l1_ws_bytes(n)) return GS_E_WORKSPACE;
@@ -560,6 +612,7 @@ int gs_l1_loss(int64_t n, const float* x, const float* y, float* loss, float* dL
 
 int gs_bce_loss(int64_t n, const float* x, const float* y, float* loss, float* dL_dx, void* workspace, size_t workspace_bytes,
                 void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (n <= 0 || !x || !y || !loss || !dL_dx || !workspace) return GS_E_BAD_ARG;
     if (workspace_bytes < l1_ws_bytes(n)) return GS_E_WORKSPACE;
     return launch_bce_loss(x, y, n, loss, dL_dx, (float*)workspace, (hipStream_t)stream);
@@ -572,6 +625,7 @@ int gs_ssim_workspace_bytes(int32_t C, int32_t H, int32_t W, size_t* out) {
 }
 int gs_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, float* ssim_out, float* dm_dmu1,
                     float* dm_dsigma1_sq, float* dm_dsigma12, void* workspace, size_t workspace_bytes, void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_out || !workspace) return GS_E_BAD_ARG;
     if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr)) return GS_E_BAD_ARG;
     if (workspace_bytes < ssim_ws_bytes(C, H, W)) return GS_E_WORKSPACE;
@@ -581,6 +635,7 @@ int gs_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const fl
 int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* dm_dmu1,
                      const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dssim, float* dL_dimg1,
                      void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dssim || !dL_dimg1)
         return GS_E_BAD_ARG;
     return launch_ssim_backward(C, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dssim, dL_dimg1,
@@ -589,12 +644,14 @@ int gs_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const f
 
 int gs_densify_stats(int32_t N, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
                      float* xyz_gradient_accum, float* denom, void* stream) {
+    GS_CAPTURE_OK_IF(stream, true);
     if (N < 0 || (N > 0 && (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom))) return GS_E_BAD_ARG;
     if (N == 0) return GS_OK;
     return launch_densify_stats(N, radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, (hipStream_t)stream);
 }
 int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, double beta2, double eps, int64_t step,
                  void* stream) {
+    GS_NO_CAPTURE(stream);  // (the step number is a host scalar: a replay would repeat the captured step's bias correction)
     if (n_tensors < 0 || n_tensors > GS_ADAM_MAX_TENSORS || (n_tensors > 0 && !tensors) || step < 1) return GS_E_BAD_ARG;
     for (int k = 0; k < n_tensors; k++) {
         const GsAdamTensor& t = tensors[k];
@@ -606,6 +663,7 @@ int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, d
 
 int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, int32_t K, float* dists, int64_t* idx,
                void* workspace, size_t workspace_bytes, void* stream) {
+    GS_NO_CAPTURE(stream);
     if (Nq < 0 || Nr <= 0 || K < 1 || K > 8 || (Nq > 0 && (!queries || !dists || !idx)) || !ref || !workspace) return GS_E_BAD_ARG;
     if (Nq == 0) return GS_OK;
     return launch_knn_points(Nq, queries, Nr, ref, K, dists, (long long*)idx, workspace, workspace_bytes, (hipStream_t)stream);
@@ -726,6 +784,7 @@ const char* gs_status_string(int code) {
         case GS_E_TOO_LARGE: return "num_rendered or tile grid exceeds the supported index space";
         case GS_E_HIP: return "HIP error";
         case GS_E_WORKSPACE: return "state/workspace buffer smaller than gs_*_bytes requires";
+        case GS_E_CAPTURE: return "the stream is being captured into a graph and this call is not capture-safe with these arguments (include/gsplat_mi355.h, \"Stream capture\"); nothing was enqueued";
         default: return "unknown status";
     }
 }

@@ -197,6 +197,8 @@ void gs_set_error(int hip_err, const char* stage);
         if (e__ != hipSuccess) { gs_set_error((int)e__, stage); return GS_E_HIP; }     \
     } while (0)
 
+// `bytes` (a multiple of 4) of zeros written by a kernel (no memset node: see "stream capture" in capi.hip)
+int gs_zero_async(void* ptr, size_t bytes, const char* stage, hipStream_t s);
 // Per-stage hipEvent timing (gs_profile_enable / gs_profile_collect); a no-op unless enabled.
 void gs_prof_begin(const char* stage, hipStream_t s);
 void gs_prof_end(hipStream_t s);

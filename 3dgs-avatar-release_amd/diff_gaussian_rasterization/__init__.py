@@ -89,13 +89,14 @@ class _GeomCache(object):
             return None
         return (id(t), t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
 
-    def key(self, settings, means3D, opacities, scales, rotations, cov3D, stream_handle=None):
+    def key(self, settings, means3D, opacities, scales, rotations, cov3D, stream_handle=None, capturing=False):
         tensors = (means3D, opacities, scales, rotations, cov3D, settings.viewmatrix, settings.projmatrix, settings.campos)
         return dict(scalars=(int(settings.image_height), int(settings.image_width), float(settings.tanfovx),
                              float(settings.tanfovy), float(settings.scale_modifier), int(means3D.shape[0]), _TILE_RECT,
                              # the cached state is only valid in stream order: a hit must come from the same stream
                              _lib.stream_handle(means3D.device) if stream_handle is None
-                             else int(stream_handle)),
+                             else int(stream_handle),
+                             bool(capturing)),  # (a state made under capture only exists inside that graph, and vice versa)
                     sigs=[self._sig(t) for t in tensors],
                     # the objects themselves: an id() can only be trusted while its object is alive
                     objs=[t for t in tensors if t is not None and t.numel() > 0])
@@ -151,6 +152,37 @@ def _capacity_for(count):
     want = count + count // 8
     step = 1 << max(want.bit_length() - 5, 0)
     return (want + step - 1) // step * step
+
+
+_is_capturing = None
+
+
+def _stream_capturing():
+    """True while the current stream is being captured into a graph (torch.cuda.graph): the forward then takes the
+    capture-safe two-phase form (kernel launches only, no host wait for the pair count)."""
+    global _is_capturing
+    if _is_capturing is None:
+        _is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
+    return bool(_is_capturing())
+
+
+# forwards issued under stream capture since the last call of captured_forwards(clear=True): what a caller needs to find
+# out, after a replay, whether the frame's pair count fitted the capacity the graph was captured with
+_captured = []
+
+
+def captured_forwards(clear=False):
+    """[(pair_count, capacity)]: for every rasterizer forward captured into a graph, a device int64 tensor (one element,
+    a view of that call's geometry state: the frame's num_rendered after a replay) and the fixed pair capacity of its
+    binning state.  A replay whose count exceeds the capacity has rendered an EMPTY frame (nothing out of bounds):
+    compare after synchronising, outside the graph, and re-capture with `GSPLAT_CAPTURE_SLACK` raised if it happens."""
+    out = list(_captured)
+    if clear:
+        del _captured[:]
+    return out
+
+
+_CAPTURE_SLACK = float(os.environ.get("GSPLAT_CAPTURE_SLACK", "0.25"))  # head-room over the last eager frame's pair count
 
 
 def _pinned_count(device):
@@ -353,11 +385,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                            keep)
             stream_h = _lib.stream_handle(dev)
             sptr = ctypes.c_void_p(stream_h)
+            capturing = _stream_capturing()
+            if capturing:
+                a.frame_stats = None  # (a kernel storing into pinned host memory is not what a graph should replay)
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
             # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
             share = _SHARE and getattr(_tls, "grad_mode", True) and any(ctx.needs_input_grad)
-            gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream_h)
+            gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream_h,
+                                    capturing)
                     if share else None)
             hit = _geom_cache.take(dev, gkey) if share else None
             if not share:
@@ -397,8 +433,40 @@ class _RasterizeGaussians(torch.autograd.Function):
                 return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
                                                    img, color, dev, a, sptr, keep)
-            count = _pinned_count(dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            if capturing:
+                # hipGraph capture (torch.cuda.graph): gs_forward waits for the pair count on the host, which a capture
+                # cannot do.  The capture-safe form is the two-phase pair at a FIXED capacity -- kernel nodes only; the
+                # count stays on the device (captured_forwards() hands out a view of it)
+                ck = (dev.index, P, W, H)
+                if ck not in _last_count:
+                    raise RuntimeError("diff_gaussian_rasterization: run one eager frame of this shape (P=%d, %dx%d) before "
+                                       "capturing it into a graph: the binning state of a captured frame has a fixed "
+                                       "capacity, sized from the last eager frame's pair count" % (P, W, H))
+                guess = _last_count[ck]
+                capacity = _capacity_for(max(int(guess * (1.0 + _CAPTURE_SLACK)), 1024))
+                bin_bytes = _size("gs_binning_bytes", capacity, W, H)
+                binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
+                _lib.check(L.gs_forward_preprocess(ctypes.byref(a), geom.data_ptr(), geom_bytes, img.data_ptr(), img_bytes,
+                                                   radii.data_ptr(), None, sptr))
+                _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), geom_bytes, binning.data_ptr(), bin_bytes,
+                                               img.data_ptr(), img_bytes, capacity, color.data_ptr(), sptr))
+                cptr = ctypes.c_void_p()
+                _lib.check(L.gs_geom_field(geom.data_ptr(), P, 5, ctypes.byref(cptr)))
+                off = int(cptr.value) - geom.data_ptr()
+                _captured.append((geom[off:off + 8].view(torch.int64), capacity))
+                num_rendered = capacity  # (the frame's own count is only known on the device)
+                if share:
+                    ctx.geom_entry = _GeomEntry(gkey, geom, binning, img, num_rendered, capacity, radii)
+                    ctx.geom_entry.color_ref = weakref.ref(color)
+                    ctx.geom_entry.means2D_id = id(means2D_in)
+                    ctx.geom_entry.allow_second = not ctx.with_opacity
+                    ctx.geom_entry.long_lists = int(a.long_lists)
+                    _geom_cache.put(dev, ctx.geom_entry)
+                return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
+                                                   opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
+                                                   color, dev, a, sptr, keep)
+            count = _pinned_count(dev)
             # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
             # previous frame's count (+ 1/8) is handed to gs_forward, which enqueues phase 2 right behind phase 1
             # against that capacity (the kernels read the count on the device) and only then waits for the count:

@@ -41,6 +41,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
+GS_E_CAPTURE = -6
 GS_ADAM_MAX_TENSORS = 16
 
 

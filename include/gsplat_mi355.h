@@ -35,6 +35,23 @@ extern "C" {
 #define GS_E_TOO_LARGE (-3)    /* num_rendered or tile count exceeds the 32-bit index space  */
 #define GS_E_HIP (-4)          /* a HIP launch or API call failed (see gs_last_hip_error)    */
 #define GS_E_WORKSPACE (-5)    /* a caller-provided buffer is smaller than gs_*_bytes says    */
+#define GS_E_CAPTURE (-6)      /* `stream` is being captured into a hipGraph and this call, with these arguments, is not
+                                * capture-safe (see "Stream capture" below); nothing was enqueued */
+
+/* ---- Stream capture (hipGraph).  Every entry point that takes a stream asks hipStreamIsCapturing first.  A call that
+ * would wait for the GPU, copy to or store into host memory, or enqueue anything but kernel launches returns
+ * GS_E_CAPTURE without enqueuing anything -- it never leaves the capture half-built or faults on replay.  Capture-safe
+ * (kernel launches only, every pointer a device pointer, no host wait):
+ *   gs_forward_preprocess  with count_host_pinned == NULL (the count stays in the geom state: gs_geom_field 5)
+ *   gs_forward_render      with a->frame_stats == NULL, at a fixed capacity (a frame whose count exceeds it renders
+ *                          empty: read the count afterwards, outside the graph)
+ *   gs_forward_shared (P > 0), gs_opacity_image, gs_backward, gs_backward_with_opacity, gs_backward_with_second,
+ *   gs_mark_visible, gs_l1_loss, gs_bce_loss, gs_ssim_*, gs_build_covariance*, gs_sh2rgb* (view_noise_host == NULL),
+ *   gs_densify_stats
+ * -- all of them with a->debug == 0 and the stage timer (gs_profile_enable) off.  Not capture-safe: gs_forward (it waits
+ * for the pair count on the host), gs_adam_step (the step number is a host scalar: a replay would repeat the captured
+ * step's bias correction), knn_dist2 / knn_points (their sorts clear tables with memset nodes: untested under replay),
+ * anything in debug mode. */
 
 /* Arguments of one rasterizer call: the fields of GaussianRasterizationSettings
  * (gaussian_renderer/__init__.py:85-98) plus the tensors of GaussianRasterizer.forward

@@ -336,10 +336,98 @@ void or_tile_ranges(int64_t D, const uint64_t* keys, int ntiles, uint32_t* range
     }
 }
 
+/* ---- threshold decisions of the compositing loop: margins, overrides, attribution ------------------------
+ * The loop below takes three yes/no decisions per (pixel, Gaussian) pair: power > 0, alpha < 1/255, T (1 - alpha) < 1e-4.
+ * A device kernel evaluates the same expressions with another exp (v_exp_f32 vs glibc expf), in the log2 domain and
+ * with FMA contraction: for a pair whose value sits within rounding of a threshold it can decide the other way, and
+ * the pixel then differs by that pair's whole contribution -- not by rounding.  To make "the only differences are
+ * such flips" a CHECKED statement (tests/test_gpu_parity.py) the oracle can
+ *   - report per pixel the smallest relative margin of any decision it took (or_render_forward_ex, `margin`),
+ *   - take a table of OVERRIDES: decisions of named (pixel, list entry) pairs forced to a given outcome, in the forward
+ *     and in the backward,
+ *   - and, given what the device produced for a pixel (colour, final T, last contributor), SEARCH for the smallest set
+ *     of decisions -- each within a stated margin of its threshold -- whose flipping reproduces it (or_explain_pixels).
+ * None of this changes the arithmetic of a pair: or_render_forward is or_render_forward_ex without overrides. */
+#define OV_SKIP 1u /* the pair is skipped whatever its power / alpha tests say     */
+#define OV_KEEP 2u /* the pair passes the power and the alpha test whatever they say */
+#define OV_STOP 4u /* the pixel is done at this pair: the T test fails             */
+#define OV_GO 8u   /* the T test passes                                            */
+
+typedef struct { uint32_t j; uint8_t act; float margin; } OrCand;
+
+/* overrides of one pixel: the slice [lo, hi) of the table sorted by key = pixel << 32 | list index */
+static void ov_slice(int n, const uint64_t* key, uint64_t pid, int* lo_out, int* hi_out) {
+    int lo = 0, hi = n;
+    const uint64_t k0 = pid << 32;
+    while (lo < hi) { int m = (lo + hi) >> 1; if (key[m] < k0) lo = m + 1; else hi = m; }
+    int e = lo;
+    while (e < n && (key[e] >> 32) == pid) e++;
+    *lo_out = lo; *hi_out = e;
+}
+static inline uint8_t ov_act(const uint64_t* key, const uint8_t* act, int lo, int hi, uint32_t j) {
+    for (int k = lo; k < hi; k++) if ((uint32_t)key[k] == j) return act[k];
+    return 0;
+}
+
+/* One pixel, front to back (A6).  okey/oact[lo, hi): this pixel's overrides.  cands (may be NULL): the decisions
+ * taken within eps[] = (power, alpha, T) relative margin of their threshold and not overridden, with the action that
+ * would flip each.  margin (may be NULL): the smallest relative margin of any decision taken. */
+static void pixel_walk(const uint32_t* point_list, uint32_t r0, uint32_t r1, const float* xy, const float* conic_opacity,
+                       const float* rgb, float pxf, float pyf, const uint64_t* okey, const uint8_t* oact, int lo, int hi,
+                       float C[3], float* T_out, uint32_t* last_out, float* margin, OrCand* cands, int* ncand, int maxc,
+                       const float* eps) {
+    float T = 1.0f;
+    C[0] = C[1] = C[2] = 0.f;
+    uint32_t contributor = 0, last = 0;
+    float mg = INFINITY;
+    for (uint32_t j = r0; j < r1; j++) {
+        contributor++;
+        const uint8_t act = lo < hi ? ov_act(okey, oact, lo, hi, j) : 0;
+        uint32_t g = point_list[j];
+        float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+        const float* co = conic_opacity + 4 * g;
+        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (act & OV_SKIP) continue;
+        const int keep = (act & OV_KEEP) != 0;
+        if (!keep && (margin || cands)) {
+            /* |power| against the size of the terms it is the sum of (nothing to decide when they are all zero) */
+            float terms = 0.5f * (fabsf(co[0]) * dx * dx + fabsf(co[2]) * dy * dy) + fabsf(co[1] * dx * dy);
+            float relp = terms > 0.f ? fabsf(power) / terms : INFINITY;
+            if (relp < mg) mg = relp;
+            if (cands && relp <= eps[0] && *ncand < maxc) cands[(*ncand)++] = (OrCand){j, power > 0.0f ? OV_KEEP : OV_SKIP, relp};
+        }
+        if (!keep && power > 0.0f) continue;
+        float alpha = fminf(0.99f, co[3] * expf(power));
+        if (!keep && (margin || cands)) {
+            float rela = fabsf(alpha * 255.0f - 1.0f);
+            if (rela < mg) mg = rela;
+            if (cands && rela <= eps[1] && *ncand < maxc) cands[(*ncand)++] = (OrCand){j, alpha < 1.0f / 255.0f ? OV_KEEP : OV_SKIP, rela};
+        }
+        if (!keep && alpha < 1.0f / 255.0f) continue;
+        float test_T = T * (1 - alpha);
+        int stop = test_T < 0.0001f;
+        if (act & OV_STOP) stop = 1;
+        else if (act & OV_GO) stop = 0;
+        else if (margin || cands) {
+            float relT = fabsf(test_T * 10000.0f - 1.0f);
+            if (relT < mg) mg = relT;
+            if (cands && relT <= eps[2] && *ncand < maxc) cands[(*ncand)++] = (OrCand){j, stop ? OV_GO : OV_STOP, relT};
+        }
+        if (stop) break; /* done: this Gaussian is NOT blended */
+        for (int c = 0; c < 3; c++) C[c] += rgb[3 * g + c] * alpha * T;
+        T = test_T;
+        last = contributor;
+    }
+    *T_out = T;
+    *last_out = last;
+    if (margin) *margin = mg;
+}
+
 /* ---- A6: render forward --------------------------------------------------------------------- */
-int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
-                      const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
-                      float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/) {
+int or_render_forward_ex(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                         const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                         int n_over, const uint64_t* over_key, const uint8_t* over_act,
+                         float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/, float* margin /*HW or NULL*/) {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
@@ -349,25 +437,13 @@ int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* poin
             for (int lx = 0; lx < BLOCK_X; lx++) {
                 int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
                 if (pxi >= W || pyi >= H) continue;
-                float pxf = (float)pxi, pyf = (float)pyi;
-                float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
-                uint32_t contributor = 0, last = 0;
-                for (uint32_t j = r0; j < r1; j++) {
-                    contributor++;
-                    uint32_t g = point_list[j];
-                    float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
-                    const float* co = conic_opacity + 4 * g;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    float alpha = fminf(0.99f, co[3] * expf(power));
-                    if (alpha < 1.0f / 255.0f) continue;
-                    float test_T = T * (1 - alpha);
-                    if (test_T < 0.0001f) break; /* done: this Gaussian is NOT blended */
-                    for (int c = 0; c < 3; c++) C[c] += rgb[3 * g + c] * alpha * T;
-                    T = test_T;
-                    last = contributor;
-                }
                 size_t pid = (size_t)pyi * W + pxi;
+                int lo = 0, hi = 0;
+                if (n_over > 0) ov_slice(n_over, over_key, (uint64_t)pid, &lo, &hi);
+                float T, C[3];
+                uint32_t last;
+                pixel_walk(point_list, r0, r1, xy, conic_opacity, rgb, (float)pxi, (float)pyi, over_key, over_act, lo, hi, C, &T,
+                           &last, margin ? margin + pid : NULL, NULL, NULL, 0, NULL);
                 final_T[pid] = T;
                 n_contrib[pid] = last;
                 for (int c = 0; c < 3; c++) out_color[(size_t)c * H * W + pid] = C[c] + T * bg[c];
@@ -375,16 +451,103 @@ int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* poin
     }
     return 0;
 }
+int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                      float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/) {
+    return or_render_forward_ex(W, H, ranges, point_list, xy, conic_opacity, rgb, bg, 0, NULL, NULL, out_color, final_T,
+                                n_contrib, NULL);
+}
+
+/* Attribution.  For each of the `npix` listed pixels: what the device produced (dev_color[3 npix] channel-major,
+ * dev_T, dev_last = its n_contrib).  Searches, by iterative deepening up to `max_flips` decisions, for a set of
+ * decisions each within eps[] of its threshold whose flipping makes this oracle's walk of the pixel reproduce the
+ * device's result: the same last contributor, final T within tol_T (relative), every channel within tol_c (absolute).
+ * status[p] = number of flips used (0: the plain walk already matches), or -1: NOT explained.  The flips found are
+ * appended to (out_key, out_act, out_margin) -- at most `cap` of them; returns their number, or -1 on overflow. */
+typedef struct {
+    const uint32_t* point_list; uint32_t r0, r1; const float *xy, *co, *rgb, *bg; float pxf, pyf;
+    const float* dev_c; float dev_T; uint32_t dev_last; float tol_c, tol_T; const float* eps; uint64_t pid;
+} ExplainCtx;
+static int explain_rec(const ExplainCtx* x, uint64_t* fkey, uint8_t* fact, float* fmargin, int nf, int depth_left) {
+    OrCand cands[24];
+    int nc = 0;
+    float C[3], T;
+    uint32_t last;
+    /* (the forced table of this pixel, sorted by list index: insertion keeps it so) */
+    pixel_walk(x->point_list, x->r0, x->r1, x->xy, x->co, x->rgb, x->pxf, x->pyf, fkey, fact, 0, nf, C, &T, &last, NULL,
+               depth_left > 0 ? cands : NULL, &nc, 24, x->eps);
+    int ok = last == x->dev_last && fabsf(T - x->dev_T) <= x->tol_T * fmaxf(T, x->dev_T);
+    for (int c = 0; ok && c < 3; c++) ok = fabsf(C[c] + T * x->bg[c] - x->dev_c[c]) <= x->tol_c;
+    if (ok) return nf;
+    if (depth_left == 0) return -1;
+    for (int k = 0; k < nc; k++) {
+        /* force the other outcome of decision k: a new table with it merged in */
+        uint64_t key2[8]; uint8_t act2[8]; float mg2[8];
+        int n2 = 0, merged = 0;
+        const uint64_t kk = (x->pid << 32) | cands[k].j;
+        for (int i = 0; i < nf; i++) {
+            if (!merged && fkey[i] == kk) { key2[n2] = kk; act2[n2] = fact[i] | cands[k].act; mg2[n2] = fmaxf(fmargin[i], cands[k].margin); n2++; merged = 1; continue; }
+            if (!merged && fkey[i] > kk) { key2[n2] = kk; act2[n2] = cands[k].act; mg2[n2] = cands[k].margin; n2++; merged = 1; }
+            key2[n2] = fkey[i]; act2[n2] = fact[i]; mg2[n2] = fmargin[i]; n2++;
+        }
+        if (!merged) { key2[n2] = kk; act2[n2] = cands[k].act; mg2[n2] = cands[k].margin; n2++; }
+        int r = explain_rec(x, key2, act2, mg2, n2, depth_left - 1);
+        if (r >= 0) { memcpy(fkey, key2, sizeof(uint64_t) * r); memcpy(fact, act2, r); memcpy(fmargin, mg2, sizeof(float) * r); return r; }
+    }
+    return -1;
+}
+int or_explain_pixels(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
+                      const float* conic_opacity, const float* rgb, const float* bg, int npix, const uint32_t* pids,
+                      const float* dev_color /*3*npix*/, const float* dev_T, const uint32_t* dev_last, const float* eps /*3*/,
+                      float tol_c, float tol_T, int max_flips, int cap, uint64_t* out_key, uint8_t* out_act,
+                      float* out_margin, int* status /*npix*/) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X;
+    (void)H;
+    if (max_flips > 6) max_flips = 6;
+    int nout = 0;
+    for (int p = 0; p < npix; p++) {
+        const uint32_t pid = pids[p];
+        const int pxi = (int)(pid % (uint32_t)W), pyi = (int)(pid / (uint32_t)W);
+        const int tile = (pyi / BLOCK_Y) * gx + pxi / BLOCK_X;
+        const float dc[3] = {dev_color[p], dev_color[(size_t)npix + p], dev_color[2 * (size_t)npix + p]};
+        ExplainCtx x = {point_list, ranges[2 * tile], ranges[2 * tile + 1], xy, conic_opacity, rgb, bg, (float)pxi, (float)pyi,
+                        dc, dev_T[p], dev_last[p], tol_c, tol_T, eps, (uint64_t)pid};
+        uint64_t fkey[8]; uint8_t fact[8]; float fmg[8];
+        int found = -1;
+        for (int d = 0; d <= max_flips && found < 0; d++) found = explain_rec(&x, fkey, fact, fmg, 0, d);
+        status[p] = found;
+        if (found > 0) {
+            if (nout + found > cap) return -1;
+            for (int i = 0; i < found; i++) { out_key[nout] = fkey[i]; out_act[nout] = fact[i]; out_margin[nout] = fmg[i]; nout++; }
+        }
+    }
+    return nout;
+}
 
 /* ---- A7: render backward -------------------------------------------------------------------- */
 /* Back-to-front per pixel with T recovered by division, exactly the recurrence of the reference
  * kernel; the nine per-Gaussian sums are accumulated in double per list entry, then folded per
  * Gaussian in list order.  Outputs (double): dL_dmean2D[2P], dL_dconic[3P] (A,B,C), dL_dopacity[P],
  * dL_dcolor[3P]. */
+int or_render_backward_ex(int P, int W, int H, int64_t D, const uint32_t* ranges, const uint32_t* point_list,
+                          const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                          int n_over, const uint64_t* over_key, const uint8_t* over_act,
+                          double* dL_dmean2D, double* dL_dconic, double* dL_dopacity, double* dL_dcolor);
 int or_render_backward(int P, int W, int H, int64_t D, const uint32_t* ranges, const uint32_t* point_list,
                        const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
                        const float* final_T, const uint32_t* n_contrib, const float* dL_dpix /*3HW*/,
                        double* dL_dmean2D, double* dL_dconic, double* dL_dopacity, double* dL_dcolor) {
+    return or_render_backward_ex(P, W, H, D, ranges, point_list, xy, conic_opacity, rgb, bg, final_T, n_contrib, dL_dpix, 0,
+                                 NULL, NULL, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+}
+/* ... with a table of overridden decisions (see "threshold decisions" above): the SKIP / KEEP outcomes are applied
+ * here, the STOP / GO outcomes are already in the n_contrib the overridden forward produced. */
+int or_render_backward_ex(int P, int W, int H, int64_t D, const uint32_t* ranges, const uint32_t* point_list,
+                          const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix /*3HW*/,
+                          int n_over, const uint64_t* over_key, const uint8_t* over_act,
+                          double* dL_dmean2D, double* dL_dconic, double* dL_dopacity, double* dL_dcolor) {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
     double* E = (double*)calloc((size_t)(D > 0 ? D : 1) * 9, sizeof(double));
     if (!E) return -1;
@@ -406,18 +569,23 @@ int or_render_backward(int P, int W, int H, int64_t D, const uint32_t* ranges, c
                 float accum_rec[3] = {0, 0, 0}, dLp[3], last_color[3] = {0, 0, 0};
                 for (int c = 0; c < 3; c++) dLp[c] = dL_dpix[(size_t)c * H * W + pid];
                 float last_alpha = 0.f;
+                int olo = 0, ohi = 0;
+                if (n_over > 0) ov_slice(n_over, over_key, (uint64_t)pid, &olo, &ohi);
                 for (uint32_t jj = r1; jj > r0; jj--) {
                     uint32_t j = jj - 1;
                     contributor--;
                     if (contributor >= last_contributor) continue;
+                    const uint8_t act = olo < ohi ? ov_act(over_key, over_act, olo, ohi, j) : 0;
+                    if (act & OV_SKIP) continue;
+                    const int keep = (act & OV_KEEP) != 0;
                     uint32_t g = point_list[j];
                     float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
                     const float* co = conic_opacity + 4 * g;
                     float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
+                    if (!keep && power > 0.0f) continue;
                     float G = expf(power);
                     float alpha = fminf(0.99f, co[3] * G);
-                    if (alpha < 1.0f / 255.0f) continue;
+                    if (!keep && alpha < 1.0f / 255.0f) continue;
                     T = T / (1.f - alpha);
                     float dchannel_dcolor = alpha * T;
                     float dL_dalpha = 0.0f;

@@ -140,30 +140,97 @@ def binning(sc, st):
                 keys=keys[:D], point_list=vals[:D], ranges=ranges)
 
 
-def render_forward(sc, st, bn):
+class Overrides(object):
+    """Decisions of the compositing loop forced to a given outcome (gs_oracle.c, "threshold decisions"): `key` =
+    pixel << 32 | index into the point list (uint64, ascending), `act` = OV_SKIP 1 / OV_KEEP 2 / OV_STOP 4 / OV_GO 8,
+    `margin` = the relative distance of each overridden decision from its threshold."""
+
+    def __init__(self, key, act, margin):
+        order = np.argsort(np.asarray(key, np.uint64), kind="stable")
+        self.key = np.ascontiguousarray(np.asarray(key, np.uint64)[order])
+        self.act = np.ascontiguousarray(np.asarray(act, np.uint8)[order])
+        self.margin = np.ascontiguousarray(np.asarray(margin, np.float32)[order])
+        assert self.key.size == self.act.size and (np.diff(self.key.astype(np.int64)) > 0).all()
+
+    def __len__(self):
+        return int(self.key.size)
+
+    def cargs(self):
+        n = len(self)
+        return c_int(n), (_ptr(self.key) if n else None), (_ptr(self.act) if n else None)
+
+
+_NO_OVERRIDES = (c_int(0), None, None)
+
+
+def render_forward(sc, st, bn, overrides=None, margin=False):
+    """A6.  `overrides`: an Overrides table (or None); `margin`: also return, per pixel, the smallest relative margin
+    of any threshold decision the walk took."""
     W, H = sc.W, sc.H
     out = np.zeros((3, H, W), np.float32)
     final_T = np.zeros((H, W), np.float32)
     n_contrib = np.zeros((H, W), np.uint32)
+    mg = np.zeros((H, W), np.float32) if margin else None
     pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
-    rc = lib().or_render_forward(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
-                                 _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
-                                 _ptr(out), _ptr(final_T), _ptr(n_contrib))
+    if overrides is None and not margin:
+        rc = lib().or_render_forward(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
+                                     _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
+                                     _ptr(out), _ptr(final_T), _ptr(n_contrib))
+    else:
+        ov = overrides.cargs() if overrides is not None else _NO_OVERRIDES
+        rc = lib().or_render_forward_ex(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
+                                        _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg), ov[0], ov[1], ov[2],
+                                        _ptr(out), _ptr(final_T), _ptr(n_contrib), _ptr(mg))
     assert rc == 0
-    return dict(color=out, final_T=final_T, n_contrib=n_contrib)
+    im = dict(color=out, final_T=final_T, n_contrib=n_contrib)
+    if margin:
+        im["margin"] = mg
+    return im
 
 
-def forward(sc):
+def forward(sc, overrides=None, margin=False):
     """Full forward: returns (color[3,H,W], radii[P]) plus every intermediate."""
     st = preprocess(sc)
     bn = binning(sc, st)
-    im = render_forward(sc, st, bn)
+    im = render_forward(sc, st, bn, overrides, margin)
     return dict(geom=st, binning=bn, image=im, color=im["color"], radii=st["radii"])
 
 
-def backward(sc, fw, dL_dpix):
+# relative margins within which a decision may be flipped to explain a device result: |power| / (size of its terms),
+# |255 alpha - 1|, |1e4 T (1 - alpha) - 1|.  The device evaluates alpha in the log2 domain with FMA contraction and
+# v_exp_f32 (a few 1e-6 relative); T is a product of up to hundreds of factors (1 - alpha), each off by that much.
+EXPLAIN_EPS = (1e-5, 2e-5, 2e-4)
+
+
+def explain_pixels(sc, fw, pids, dev_color, dev_final_T, dev_n_contrib, eps=EXPLAIN_EPS, tol_c=None, tol_T=1e-4, max_flips=3):
+    """Attribution of device/oracle differences to threshold decisions (or_explain_pixels).  `pids`: flat pixel
+    indices; dev_*: the device's full images.  Returns (status[len(pids)] -- flips used, -1 = NOT explained --, Overrides)."""
+    W, H = sc.W, sc.H
+    st, bn = fw["geom"], fw["binning"]
+    pids = np.ascontiguousarray(np.asarray(pids, np.uint32).reshape(-1))
+    n = int(pids.size)
+    dc = np.ascontiguousarray(np.asarray(dev_color, np.float32).reshape(3, -1)[:, pids])
+    dT = np.ascontiguousarray(np.asarray(dev_final_T, np.float32).reshape(-1)[pids])
+    dl = np.ascontiguousarray(np.asarray(dev_n_contrib, np.uint32).reshape(-1)[pids])
+    if tol_c is None:
+        tol_c = 1e-5 * max(float(np.abs(fw["color"]).max()), 1e-30)
+    cap = max(8 * n, 8)
+    key, act, mg = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8), np.zeros(cap, np.float32)
+    status = np.zeros(max(n, 1), np.int32)
+    e = np.ascontiguousarray(np.asarray(eps, np.float32))
+    pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
+    m = lib().or_explain_pixels(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]), _ptr(st["conic_opacity"]),
+                                _ptr(st["rgb"]), _ptr(sc.bg), c_int(n), _ptr(pids), _ptr(dc), _ptr(dT), _ptr(dl), _ptr(e),
+                                c_float(tol_c), c_float(tol_T), c_int(max_flips), c_int(cap), _ptr(key), _ptr(act), _ptr(mg),
+                                _ptr(status))
+    assert m >= 0
+    return status[:n], Overrides(key[:m], act[:m], mg[:m])
+
+
+def backward(sc, fw, dL_dpix, overrides=None):
     """Full backward for dL/dcolor = dL_dpix[3,H,W]; returns the eight gradient tensors of the
-    reference wrapper (A3) plus the per-Gaussian 2-D intermediates."""
+    reference wrapper (A3) plus the per-Gaussian 2-D intermediates.  `overrides`: the table the forward `fw` was
+    rendered with (its final_T / n_contrib already carry the stop decisions)."""
     P, W, H = sc.P, sc.W, sc.H
     st, bn, im = fw["geom"], fw["binning"], fw["image"]
     g = np.ascontiguousarray(np.asarray(dL_dpix, np.float32).reshape(3, H, W))
@@ -172,10 +239,11 @@ def backward(sc, fw, dL_dpix):
     d_op = np.zeros(P, np.float64)
     d_col = np.zeros((P, 3), np.float64)
     pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
-    rc = lib().or_render_backward(c_int(P), c_int(W), c_int(H), c_int64(bn["D"]), _ptr(bn["ranges"]), _ptr(pl),
-                                  _ptr(st["xy"]), _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
-                                  _ptr(im["final_T"]), _ptr(im["n_contrib"]), _ptr(g),
-                                  _ptr(d_mean2D), _ptr(d_conic), _ptr(d_op), _ptr(d_col))
+    ov = overrides.cargs() if overrides is not None else _NO_OVERRIDES
+    rc = lib().or_render_backward_ex(c_int(P), c_int(W), c_int(H), c_int64(bn["D"]), _ptr(bn["ranges"]), _ptr(pl),
+                                     _ptr(st["xy"]), _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg),
+                                     _ptr(im["final_T"]), _ptr(im["n_contrib"]), _ptr(g), ov[0], ov[1], ov[2],
+                                     _ptr(d_mean2D), _ptr(d_conic), _ptr(d_op), _ptr(d_col))
     assert rc == 0
     m2 = d_mean2D.astype(np.float32)
     cn = d_conic.astype(np.float32)

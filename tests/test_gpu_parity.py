@@ -5,9 +5,17 @@ image and gradients within 1e-5 relative to the per-tensor maximum, fp32.
 A note on the float bar: alpha is compared against 1/255 and T against 1e-4 per (pixel, Gaussian)
 pair; the device's v_exp_f32 and glibc's expf differ in the last bits, so out of ~1e6-1e9 pairs a few
 land on opposite sides of a threshold (the real CUDA kernel has the same property against any CPU
-restatement).  Such a flip moves one pixel by up to T*alpha*|c| ~ 4e-3.  The float assertions below
-therefore bound BOTH the bulk error (<= 1e-5 of the tensor maximum for all but a 2e-5 fraction of
-elements) and the outliers (<= 1e-2 absolute for the image)."""
+restatement).  Such a flip moves one pixel by up to T*alpha*|c| ~ 4e-3.
+
+Round 4: that explanation is CHECKED, not assumed, in the full-size tests (`_attribute`).  Every pixel where the
+device and the oracle disagree (last contributor, final T beyond 1e-4 relative, colour beyond 1e-5 of the maximum) is
+handed to the oracle's search (or_explain_pixels): it must find decisions, each within EXPLAIN_EPS of its threshold
+(|power| <= 1e-5 of its terms, |255 alpha - 1| <= 2e-5, |1e4 T (1 - alpha) - 1| <= 2e-4), whose flipping makes the
+oracle's own walk reproduce the device's pixel -- unattributed pixels = 0 is asserted.  Image, final_T, n_contrib and
+ALL gradients are then compared with the oracle CONDITIONED on those decisions (the same arithmetic, the named
+near-threshold decisions taken the device's way), with no exempt fraction for the image and n_contrib.  The smaller
+tests keep the older form: a bulk bound (<= 1e-5 of the tensor maximum for all but a small fraction of the elements)
+plus a cap on the outliers (<= 1e-2 absolute for the image)."""
 import math
 
 import numpy as np
@@ -100,6 +108,50 @@ def _report(case, tensor, got, want, extra=None):
     return rec
 
 
+def _attribute(oracle, sc, fw, dev_color, dev_final_T, dev_n_contrib, tag):
+    """Attribution of every device/oracle difference in the forward to threshold decisions (see the module docstring).
+    Returns (the forward state of the oracle CONDITIONED on the decisions found, the override table).  Asserts that no
+    differing pixel is left unexplained, and that the conditioned oracle then agrees with the device on every pixel:
+    n_contrib exactly, final_T and colour within 1e-5 of the maximum, no exempt fraction."""
+    oc, oT, on = fw["color"], fw["image"]["final_T"], fw["image"]["n_contrib"]
+    m = max(float(np.abs(oc).max()), 1e-30)
+    dev_color = np.asarray(dev_color, np.float32).reshape(oc.shape)
+    dT = np.asarray(dev_final_T, np.float32).reshape(oT.shape)
+    dn = np.asarray(dev_n_contrib, np.uint32).reshape(on.shape)
+    differs = (dn != on) | (np.abs(dT - oT) > 1e-4 * np.maximum(dT, oT)) | (np.abs(dev_color - oc).max(0) > 1e-5 * m)
+    pids = np.flatnonzero(differs.reshape(-1))
+    status, ov = oracle.explain_pixels(sc, fw, pids, dev_color, dT, dn)
+    im = oracle.render_forward(sc, fw["geom"], fw["binning"], ov)
+    fwc = dict(fw, image=im, color=im["color"])
+    err = np.abs(dev_color - im["color"]) / m
+    kinds = {1: "skip", 2: "keep", 4: "stop", 8: "go"}
+    rec = {"pixels": int(differs.size), "pixels_differing_before": int(pids.size), "unattributed_pixels": int((status < 0).sum()),
+           "flipped_decisions": len(ov), "flips_per_pixel_max": int(status.max()) if status.size else 0,
+           "largest_margin_of_a_flipped_decision": float(ov.margin.max()) if len(ov) else 0.0,
+           "margins_allowed_power_alpha_T": list(oracle.EXPLAIN_EPS),
+           "flips_by_outcome": {kinds.get(int(a), str(int(a))): int((ov.act == a).sum()) for a in np.unique(ov.act)},
+           "image_max_rel_err_after": float(err.max()), "n_contrib_mismatches_after": int((dn != im["n_contrib"]).sum()),
+           "final_T_max_abs_err_after": float(np.abs(dT - im["final_T"]).max())}
+    _REPORT.setdefault(tag, {})["attribution"] = rec
+    _report(tag, "color_vs_conditioned_oracle", dev_color, im["color"], extra=rec)
+    assert rec["unattributed_pixels"] == 0, "%s: %d of %d differing pixels are not explained by decisions within %r of a threshold" % (
+        tag, rec["unattributed_pixels"], pids.size, oracle.EXPLAIN_EPS)
+    assert rec["n_contrib_mismatches_after"] == 0, tag
+    assert err.max() <= TOL, "%s: image off by %.3g of the maximum from the conditioned oracle" % (tag, err.max())
+    assert rec["final_T_max_abs_err_after"] <= TOL, tag
+    return fwc, ov
+
+
+# Gradients against the CONDITIONED oracle: the north star's 1e-5 of the tensor maximum.  Measured on all 25 full-size
+# cases (profiles/r04_parity_report.json): NO element beyond 1e-5 (largest 8.1e-6: dL/dopacity on the avatar frame, sums
+# over lists of thousands of entries in another order; typically 1-3e-6), with at most 50 flipped decisions per frame in
+# the conditioning (config 5; 16 at config 3), each within 1.6e-5 of its threshold.  The allowance below -- one element
+# in a million up to 3e-5 -- is head-room for rounding changes between builds, not something a recorded run uses.
+# (Until round 3, against the plain oracle: 2e-4 of the elements exempt -- 1e-3 at config 1 -- up to 2e-3 of the maximum.)
+COND_GRAD_FRAC = 1e-6
+COND_GRAD_CAP = 3e-5
+
+
 COMBOS = [("sh", "scale_rot", 3), ("precomp", "cov", 3), ("sh", "cov", 1), ("precomp", "scale_rot", 0), ("sh", "scale_rot", 2)]
 
 
@@ -176,7 +228,12 @@ def test_backward_matches_oracle(oracle, tile_rect, color_mode, cov_mode, deg):
     sc = helpers.oracle_scene(cloud, cam, bg=bg, color_mode=color_mode, cov_mode=cov_mode, tile_rect=tile_rect)
     fw = oracle.forward(sc)
     gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
-    want = oracle.backward(sc, fw, gimg.numpy())
+    from gsplat_mi355 import debug
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             **_inputs(cloud, cam, color_mode, cov_mode, dev))
+    tag = "small backward %s/%s deg %d tile_rect=%d" % (color_mode, cov_mode, deg, tile_rect)
+    fwc, ov = _attribute(oracle, sc, fw, st["color"], st["image"]["final_T"], st["image"]["n_contrib"], tag)
+    want = oracle.backward(sc, fwc, gimg.numpy(), ov)
 
     kw = {k: v.clone().requires_grad_(True) for k, v in _inputs(cloud, cam, color_mode, cov_mode, dev).items()}
     means3D = cloud.xyz.to(dev).requires_grad_(True)
@@ -186,7 +243,7 @@ def test_backward_matches_oracle(oracle, tile_rect, color_mode, cov_mode, deg):
     color, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, **kw)
     (color * gimg.to(dev)).sum().backward()
     assert np.array_equal(radii.cpu().numpy(), fw["radii"])
-    _bulk_close(color.detach().cpu().numpy(), fw["color"], name="color")
+    assert np.array_equal(color.detach().cpu().numpy(), st["color"])  # (the wrapper and the two-phase C calls: same bits)
     got = dict(means3D=means3D.grad, means2D=means2D.grad, opacities=opac.grad)
     names = dict(shs="sh", colors_precomp="colors_precomp", scales="scales", rotations="rotations",
                  cov3D_precomp="cov3D_precomp")
@@ -195,8 +252,8 @@ def test_backward_matches_oracle(oracle, tile_rect, color_mode, cov_mode, deg):
     for name, gt in got.items():
         assert gt is not None, name
         w = want[name].reshape(gt.shape)
-        # gradients sum ~1e3 float terms per Gaussian in a different order than the oracle: allow 2e-5 bulk
-        _bulk_close(gt.cpu().numpy(), w, tol=2e-5, frac=1e-4, name=name, cap=GRAD_CAP)
+        # every element within 1e-5 of the tensor maximum of the oracle conditioned on the attributed decisions
+        _bulk_close(gt.cpu().numpy(), w, tol=1e-5, frac=0.0, name=name)
         assert np.abs(w).max() > 0
     culled = fw["radii"] == 0
     for name, gt in got.items():
@@ -656,7 +713,7 @@ def _sorted_list_properties(st):
 
 
 def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_pairs=0, extra_properties=False,
-                    layout="box", sh_degree=3, grad_frac=2e-4):
+                    layout="box", sh_degree=3, grad_frac=None):
     """One BASELINE configuration at FULL size through the HIP path against the oracle in the same binning mode:
     integers (radii, tiles_touched, num_rendered, the sorted (tile, depth) list, the tile ranges) bit-exact; image,
     final_T and all six gradient tensors inside the float bar with bounded outliers; errors recorded in the parity
@@ -687,13 +744,16 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
             extra={"num_rendered": int(st["D"]), "pixels_with_a_different_last_contributor": flips,
                    "max_abs_err": float(np.abs(st["color"] - fw["color"]).max())})
     _report(tag, "final_T", st["image"]["final_T"], fw["image"]["final_T"])
+    # (the plain oracle: bulk bound + cap, as until round 3 -- kept as a second, independent statement)
     _bulk_close(st["color"], fw["color"], name="color " + tag)
     assert np.abs(st["color"] - fw["color"]).max() < 1e-2
     _bulk_close(st["image"]["final_T"], fw["image"]["final_T"], name="final_T " + tag)
     assert flips < 1e-4 * W * H
+    # every difference attributed to decisions at a threshold; from here on the oracle conditioned on them
+    fwc, ov = _attribute(oracle, sc, fw, st["color"], st["image"]["final_T"], st["image"]["n_contrib"], tag)
 
     g1 = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
-    want = oracle.backward(sc, fw, g1.numpy())
+    want = oracle.backward(sc, fwc, g1.numpy(), ov)
 
     def grads(gimg):
         leaves = dict(means3D=cloud.xyz.to(dev).requires_grad_(True),
@@ -711,9 +771,7 @@ def _full_size_case(oracle, case, n, W, H, heavy_tail, tile_rect, frame=0, min_p
     for k, v in got.items():
         w = want[names[k]].reshape(v.shape)
         _report(tag, "dL_d" + k, v, w)
-        # the north star's 1e-5 of the tensor maximum, for all but 2e-4 of the elements (measured: <= 1e-4 of them, the
-        # 99.99th percentile at ~2e-6 -- profiles/r02_parity_report.json), every element within GRAD_CAP
-        _bulk_close(v, w, tol=1e-5, frac=grad_frac, name=k + " " + tag, cap=GRAD_CAP)
+        _bulk_close(v, w, tol=1e-5, frac=COND_GRAD_FRAC if grad_frac is None else grad_frac, name=k + " " + tag, cap=COND_GRAD_CAP)
     culled = fw["radii"] == 0
     for k, v in got.items():
         assert (v[culled] == 0).all(), k
@@ -731,10 +789,10 @@ def test_full_size_config1_shape_10k_256_sh0_on_the_hip_path(oracle, tile_rect):
     """BASELINE config 1 (dummy_dataset: 10k random Gaussians, 256 x 256, SH degree 0) is by definition the no-GPU
     plumbing configuration and runs on the CPU oracle (tests/test_oracle.py); this is the same shape through the HIP
     path, forward + backward against the oracle in both binning modes, so that no BASELINE shape is left unexercised."""
-    # (10 000 Gaussians: a tensor has 10-40 k elements, so the handful of threshold flips of a frame -- see the module
-    # docstring -- is a larger FRACTION than at 200k; same 1e-5 bar, same cap, 1e-3 of the elements exempt)
-    _full_size_case(oracle, "config1 10k/256x256 SH0", 10000, 256, 256, 0.0, tile_rect, min_pairs=10000, sh_degree=0,
-                    grad_frac=1e-3)
+    # (10 000 Gaussians: a tensor has 10-40 k elements.  Until round 3 the handful of threshold flips of a frame needed 1e-3
+    # of them exempt -- dL_dopacities passed at exactly 10 of 10 000; with the flips attributed and conditioned on, the
+    # same bar as every other shape)
+    _full_size_case(oracle, "config1 10k/256x256 SH0", 10000, 256, 256, 0.0, tile_rect, min_pairs=10000, sh_degree=0)
 
 
 def test_full_size_config3_200k_1024_forward_backward(oracle, tile_rect):
@@ -844,11 +902,13 @@ def _two_call_step(oracle, monkeypatch, scene, bg, mode, use):
     oracle.backward(colour pass) + oracle.backward(colours = 1 pass) at the full-size bar.
 
     mode "second-call": the reference's unmodified two rasterizer calls.  The second one is served from the first one's
-    geometry (gs_forward_shared; colours = 1: second_ones_kernel writes 1 - T) and both images are differentiated by ONE
-    backward pass (gs_backward_with_second: render_bwd_kernel<2>).  mode "with-opacity": one call with with_opacity=True
+    geometry (gs_forward_shared; colours = 1: the recolouring launch's other workgroups write 1 - T speculatively and the
+    render launch behind it leaves the image alone) and both images are differentiated by ONE backward pass
+    (gs_backward_with_second; colours all ones: render_bwd_kernel<3>, MODE 0's loop with the closed-form second term;
+    arbitrary second colours: render_bwd_kernel<2>).  mode "with-opacity": one call with with_opacity=True
     (gs_opacity_image, gs_backward_with_opacity: render_bwd_kernel<1>)."""
     import diff_gaussian_rasterization as dgr
-    from gsplat_mi355 import _lib
+    from gsplat_mi355 import _lib, debug
     from gsplat_mi355.render import Pipe, render
     assert dgr._SHARE and dgr._FUSE_SECOND and dgr._SPECULATE and dgr._LONG_LISTS == "0"  # the defaults are under test
     dev = torch.device("cuda:0")
@@ -889,11 +949,24 @@ def _two_call_step(oracle, monkeypatch, scene, bg, mode, use):
     _bulk_close(color, fw["color"], name="color " + tag)
     _bulk_close(opa[0], fw1["color"][0], name="opacity image " + tag)
     assert np.abs(color - fw["color"]).max() < 1e-2 and np.abs(opa[0] - fw1["color"][0]).max() < 1e-2
+    # Attribution (module docstring): the device's per-pixel records of this frame (the same inputs through the two-phase
+    # C calls: same kernels, same bits as the wrapper's speculative path -- test_speculative_capacity_*), every
+    # difference explained by decisions at a threshold, then BOTH images and all gradients against the oracle
+    # conditioned on them.  The two passes share geometry, hence decisions: one override table serves both.
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), pc.xyz.detach(), pc.opacity.detach(),
+                             colors_precomp=pc.colors.detach(), cov3D_precomp=pc.cov6.detach())
+    assert np.array_equal(st["color"], color)
+    fwc, ov = _attribute(oracle, sc, fw, color, st["image"]["final_T"], st["image"]["n_contrib"], tag)
+    im1 = oracle.render_forward(sc1, fw1["geom"], fw1["binning"], ov)
+    fw1c = dict(fw1, image=im1, color=im1["color"])
+    m1 = max(float(np.abs(im1["color"]).max()), 1e-30)
+    assert np.abs(opa[0] - im1["color"][0]).max() <= TOL * m1, "opacity image vs the conditioned oracle: " + tag
+    _report(tag, "opacity_image_vs_conditioned_oracle", opa[0], im1["color"][0])
 
     gop = np.zeros((3, H, W), np.float32)
     gop[0] = g1.numpy()[0]  # the reference keeps channel 0 of the second call's image (`[:1]`)
-    b1 = oracle.backward(sc1, fw1, gop)
-    b0 = oracle.backward(sc, fw, g0.numpy()) if use == "both" else None
+    b1 = oracle.backward(sc1, fw1c, gop, ov)
+    b0 = oracle.backward(sc, fwc, g0.numpy(), ov) if use == "both" else None
     got = dict(means3D=pc.xyz.grad, means2D=pkg.viewspace_points.grad, opacities=pc.opacity.grad,
                colors_precomp=pc.colors.grad, cov3D_precomp=pc.cov6.grad)
     culled = fw["radii"] == 0
@@ -911,7 +984,7 @@ def _two_call_step(oracle, monkeypatch, scene, bg, mode, use):
         if np.abs(w).max() == 0:
             assert (v == 0).all(), k
             continue
-        _bulk_close(v, w, tol=1e-5, frac=2e-4, name=k + " " + tag, cap=GRAD_CAP)
+        _bulk_close(v, w, tol=1e-5, frac=COND_GRAD_FRAC, name=k + " " + tag, cap=COND_GRAD_CAP)
         assert (v[culled] == 0).all(), k
 
 
