@@ -27,7 +27,7 @@ STRICT = {"preprocess.hip", "knn.hip"}
 # nothing and the register shuffling the SLP vectoriser adds to form the pairs costs VALU slots
 NO_SLP = {"render_fwd.hip", "render_bwd.hip"}
 SOURCES = ["capi.hip", "preprocess.hip", "radix_sort.hip", "depth_sort.hip", "binning.hip", "render_fwd.hip", "render_bwd.hip",
-           "gaussian_bwd.hip", "knn.hip", "loss.hip", "prepass.hip", "optim.hip"]
+           "gaussian_bwd.hip", "knn.hip", "loss.hip", "prepass.hip", "optim.hip", "debug_stats.hip"]
 
 
 def hipcc():

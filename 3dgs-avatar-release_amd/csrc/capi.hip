@@ -38,6 +38,7 @@ struct ProfRec { const char* name; hipEvent_t a, b; };
 struct ProfState {
     bool on = false;
     bool armed = false;  // the current stage is being timed
+    int nested = 0;      // stage scopes opened inside the one being timed (they belong to it: no record of their own)
     char filter[32] = {0};
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -58,6 +59,7 @@ static bool profiling_on() { return g_prof.on; }
 void gs_prof_begin(const char* stage, hipStream_t s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.armed) { g_prof.nested++; return; }
     g_prof.armed = g_prof.on && (g_prof.filter[0] == 0 || strcmp(g_prof.filter, stage) == 0);
     if (!g_prof.armed) return;
     ProfRec r{stage, g_prof.get(), g_prof.get()};
@@ -68,6 +70,7 @@ void gs_prof_end(hipStream_t s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof.armed || g_prof.recs.empty()) return;
+    if (g_prof.nested > 0) { g_prof.nested--; return; }
     (void)hipEventRecord(g_prof.recs.back().b, s);
     g_prof.armed = false;
 }
@@ -130,7 +133,42 @@ int gs_zero_async(void* ptr, size_t bytes, const char* stage, hipStream_t s) {
     return GS_OK;
 }
 
+// shader clock under a VALU-bound load: an FMA stream on every SIMD; the first lane of every workgroup adds its
+// s_memtime ticks (shader cycles) and s_memrealtime ticks (100 MHz) to out[0] / out[1]
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, float seed, float* __restrict__ sink) {
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = seed + (float)i + (float)threadIdx.x * 1e-3f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) sum += a[i];
+    if (sum == 12345.678f) sink[0] = sum;  // (keeps the chains alive; never true in practice)
+    if (threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&out[0], t1 - t0);
+        atomicAdd(&out[1], r1 - r0);
+    }
+}
+
 extern "C" {
+
+int gs_clock_probe(uint64_t* ticks, int32_t iters, void* stream) {
+    if (!ticks || iters <= 0) return GS_E_BAD_ARG;
+    GS_NO_CAPTURE(stream);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = gs_zero_async(ticks, 32, "clock_probe.zero", s);
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(2048), dim3(256), 0, s, (unsigned long long*)ticks, iters, 1.0f, (float*)(ticks + 2));
+    GS_LAUNCH_CHECK("clock_probe", 0, s);
+    return GS_OK;
+}
 
 int gs_geom_bytes(int32_t P, size_t* out) {
     if (!out || P < 0) return GS_E_BAD_ARG;
@@ -240,6 +278,7 @@ int gs_forward_preprocess(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
 static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* img,
                           size_t img_bytes, int64_t cap, float* out_color, void* stream, bool totals_zeroed) {
     if (!geom || !img || !out_color || cap < 0 || (cap > 0 && !binning)) return GS_E_BAD_ARG;
+    if (a->l1_target && !a->l1_loss) return GS_E_BAD_ARG;  // the fused L1 loss needs somewhere to put its value
     if (cap > GS_MAX_PAIRS) return GS_E_TOO_LARGE;
     const GeomLayout L = geom_layout(a->P);
     const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
@@ -287,6 +326,9 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         ql.mark_quads = (size_t)cap;
         ql.marks_flag = (uint32_t*)(b + B.marks_flag);
     }
+    ql.l1_target = a->l1_target;  // the fused L1 loss rides in the render launch (+ its one-workgroup final sum)
+    ql.l1_part = (float*)(im + I.l1_part);
+    ql.l1_loss = a->l1_loss;
     { StageScope sc_("render_fwd", s);
     rc = launch_render_forward((const float*)(g + L.rec), point_list, ranges, (const uint32_t*)(im + I.order), a->bg,
                                a->W, a->H, out_color, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib), ql, s); }
@@ -449,7 +491,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
     GS_CAPTURE_OK_IF(stream, a && !a->debug);
     int rc = validate(a);
     if (rc != GS_OK) return rc;
-    if (!geom || !img || !out_color || !dL_dpix || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch)) return GS_E_BAD_ARG;
+    if (!geom || !img || !out_color || (!dL_dpix && !a->l1_target) || !gr || D < 0 || (D > 0 && !binning) || (a->P > 0 && !scratch))
+        return GS_E_BAD_ARG;
     if (a->P > 0 && (!radii || !gr->dL_dmeans3D || !gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dcov3D))
         return GS_E_BAD_ARG;
     if (a->P > 0 && a->shs && !gr->dL_dsh) return GS_E_BAD_ARG;
@@ -499,7 +542,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         { StageScope sc_("render_bwd", s);
         rc = launch_render_backward((const float*)(g + L.rec), (const uint32_t*)(im + I.ranges), order_b, a->W, a->H, ql,
                                     out_color, dL_dpix, dL_dopacity_img, (const float*)(im + I.final_T), a->bg, (float*)scratch, q8,
-                                    second ? &si : nullptr, s); }
+                                    second ? &si : nullptr, L1Grad{a->l1_target, a->l1_grad}, s); }
         if (rc != GS_OK) return rc;
         if (a->debug) {
             hipError_t e = hipStreamSynchronize(s);
@@ -667,6 +710,24 @@ int knn_points(int32_t Nq, const float* queries, int32_t Nr, const float* ref, i
     if (Nq < 0 || Nr <= 0 || K < 1 || K > 8 || (Nq > 0 && (!queries || !dists || !idx)) || !ref || !workspace) return GS_E_BAD_ARG;
     if (Nq == 0) return GS_OK;
     return launch_knn_points(Nq, queries, Nr, ref, K, dists, (long long*)idx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int gs_pair_stats(const GsFwdArgs* a, const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes, const void* img,
+                  size_t img_bytes, int64_t D, uint64_t* counts, void* stream) {
+    GS_NO_CAPTURE(stream);
+    int rc = validate(a);
+    if (rc != GS_OK) return rc;
+    if (!geom || !img || !counts || D < 0 || (D > 0 && !binning)) return GS_E_BAD_ARG;
+    const GeomLayout L = geom_layout(a->P);
+    const ImgLayout I = img_layout(a->W, a->H, a->long_lists);
+    const BinLayout B = bin_layout(D);
+    if (geom_bytes < L.total || img_bytes < I.total || (D > 0 && binning_bytes < B.total)) return GS_E_WORKSPACE;
+    const char* g = (const char*)geom;
+    const char* b = (const char*)binning;
+    const char* im = (const char*)img;
+    return launch_pair_stats((const float*)(g + L.rec), D > 0 ? (const uint32_t*)(b + B.point_list) : nullptr,
+                             (const uint32_t*)(im + I.ranges), (const uint32_t*)(im + I.n_contrib), a->W, a->H,
+                             (unsigned long long*)counts, (hipStream_t)stream);
 }
 
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out) {

@@ -149,7 +149,7 @@ int gs_tune_get(int key);
 #endif
 
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, all_ones, tile_zero_bytes, ckpt, ck_start, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, all_ones, tile_zero_bytes, l1_part, ckpt, ck_start, total;
     int gx, gy, bwd_chunks;
 };
 // `long_lists`: GsFwdArgs.long_lists (the few-long-lists machinery on an image of any size)
@@ -176,6 +176,7 @@ static inline ImgLayout img_layout(int W, int H, int long_lists = 0) {
     // recolor_kernel): the one-pass backward of both images then needs no colours of the second image at all
     L.all_ones = take(4);
     L.tile_zero_bytes = L.all_ones + 4 - L.tile_tot;
+    L.l1_part = take(nt * 16);  // per quadrant: sum |out_color - l1_target| over its pixels (GsFwdArgs.l1_target)
     L.bwd_chunks = few_long_lists_mode((int)nt, long_lists) ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
@@ -494,6 +495,9 @@ int launch_sh2rgb_bwd(int N, int deg, int M, const float* shs, const float* xyz,
 // fused L1 image loss (loss.hip): loss[0] = mean |x - y|, grad = sign(x - y) / n
 size_t l1_ws_bytes(int64_t n);
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
+// loss[0] = (partial[0] + ... + partial[nparts - 1], in a fixed order) * inv_n  (the second pass of the L1 / BCE losses; also
+// the fused L1's, whose partials come from the render launch)
+int launch_loss_final(const float* partial, int nparts, float inv_n, float* loss, hipStream_t s);
 int launch_bce_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s);
 // SSIM of two (C,H,W) images + the three partial-derivative maps its backward filters (loss.hip)
 size_t ssim_ws_bytes(int C, int H, int W);
@@ -536,6 +540,10 @@ struct QuadLists {
     size_t mark_quads = 0;
     uint32_t* marks_flag = nullptr;
     uint32_t* all_ones = nullptr;  // (a second render) the image state's "this image is 1 - T of the first render" word
+    // fused L1 loss (GsFwdArgs.l1_target): the target image, one partial sum per quadrant, the mean
+    const float* l1_target = nullptr;
+    float* l1_part = nullptr;
+    float* l1_loss = nullptr;
 };
 int launch_render_forward(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* order,
                           const float* bg, int W, int H, float* out_color, float* final_T, uint32_t* n_contrib,
@@ -551,10 +559,12 @@ struct SecondImage {
     const float4* ckpt;      // its checkpoints (chunked backward), or null
     const uint32_t* all_ones;  // a word of its image state: 1 = its colours are all (1, 1, 1) (ImgLayout.all_ones)
 };
+// fused L1 loss in the backward: dL/dpixel += sign(out_color - target) * (grad ? *grad : 1) / (3 H W)  (target null: off)
+struct L1Grad { const float* target; const float* grad; };
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
-                           hipStream_t s);
+                           L1Grad l1, hipStream_t s);
 // opacity render of a finished forward: (1 - final_T) + final_T * bg0 per pixel (render_fwd.hip)
 int launch_opacity_image(const float* final_T, const float* bg, int W, int H, float* out, hipStream_t s);
 int launch_gaussian_backward(const GsFwdArgs& a, const int32_t* radii, const float* rec, const uint32_t* tiles,
@@ -580,5 +590,8 @@ static inline size_t scratch_total_bytes(int64_t D, int P, int ntiles) {
     return scratch_rows_bytes(D) + scratch_sums_bytes(P) + align_up((size_t)ntiles * 4, 256);  // (the row marks: BinLayout)
 }
 
+// report counters (debug_stats.hip): out[0] = pairs composited (alpha >= 1/255 before the pixel is done), out[1] = sum of n_contrib
+int launch_pair_stats(const float* rec, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* n_contrib, int W, int H,
+                      unsigned long long* out, hipStream_t s);
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_ws_bytes(int P);

@@ -93,6 +93,13 @@ int launch_bce_loss(const float* x, const float* y, int64_t n, float* loss, floa
     return GS_OK;
 }
 
+int launch_loss_final(const float* partial, int nparts, float inv_n, float* loss, hipStream_t s) {
+    // (no stage scope of its own: the fused L1 calls it from inside the render_fwd stage, and stage scopes do not nest)
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, partial, nparts, inv_n, loss);
+    GS_LAUNCH_CHECK("loss_final", 0, s);
+    return GS_OK;
+}
+
 int launch_l1_loss(const float* x, const float* y, int64_t n, float* loss, float* grad, float* partial, hipStream_t s) {
     const int blocks = l1_blocks(n);
     const float inv_n = 1.0f / (float)n;

@@ -60,8 +60,76 @@ template <bool SECOND>
 __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], unsigned long long mask, float Gd, float dx,
                                                  float dy, float tdx, float tdy, float wgt, float gx, float gy,
                                                  float gz, unsigned long long m1, uint32_t lds_addr, bwd_f4& q0, bwd_f4& q1,
-                                                 bwd_f4& q2) {
+                                                 bwd_f4& q2, float& rot0, float& rot1) {
     unsigned long long save;
+#ifdef GS_SWITCH_ONE_BLOCK
+    // Issue and wait inside ONE asm statement (as switch_entry): the compiler never sees a point where loads into q0 / q1 /
+    // q2 are in flight.  The first statement is the X set alone; the second issues the reads, runs the Y set (and the
+    // caller's two ring rotations, `rot0` / `rot1`) in their shadow and waits.  The 30-operand limit of an asm statement
+    // is what keeps the X set out of it.
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"
+        "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"
+        "v_fmac_f32 %[x2], %[tdx], %[dx]\n\t"
+        "v_fmac_f32 %[x3], %[tdx], %[dy]\n\t"
+        "v_fmac_f32 %[x4], %[tdy], %[dy]\n\t"
+        "v_add_f32 %[x5], %[x5], %[Gd]\n\t"
+        "v_fmac_f32 %[x6], %[w], %[gx]\n\t"
+        "v_fmac_f32 %[x7], %[w], %[gy]\n\t"
+        "v_fmac_f32 %[x8], %[w], %[gz]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]),
+          [x7] "+v"(x[7]), [x8] "+v"(x[8]), [sv] "=&s"(save)
+        : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx),
+          [gy] "v"(gy), [gz] "v"(gz)
+        : "scc");
+#define GS_ACC_Y                                     \
+        "s_andn2_b64 exec, %[sv], %[m]\n\t"          \
+        "v_fmac_f32 %[y0], %[Gd], %[dx]\n\t"         \
+        "v_fmac_f32 %[y1], %[Gd], %[dy]\n\t"         \
+        "v_fmac_f32 %[y2], %[tdx], %[dx]\n\t"        \
+        "v_fmac_f32 %[y3], %[tdx], %[dy]\n\t"        \
+        "v_fmac_f32 %[y4], %[tdy], %[dy]\n\t"        \
+        "v_add_f32 %[y5], %[y5], %[Gd]\n\t"          \
+        "v_fmac_f32 %[y6], %[w], %[gx]\n\t"          \
+        "v_fmac_f32 %[y7], %[w], %[gy]\n\t"          \
+        "v_fmac_f32 %[y8], %[w], %[gz]\n\t"          \
+        "s_mov_b64 exec, %[sv]\n\t"                  \
+        "v_mov_b32_dpp %[r0], %[r0] row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_mov_b32_dpp %[r1], %[r1] row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "s_waitcnt lgkmcnt(0)"
+#define GS_ACC_Y_OUT [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), \
+                     [y6] "+v"(y[6]), [y7] "+v"(y[7]), [y8] "+v"(y[8]), [q0] "+v"(q0), [q1] "+v"(q1), [r0] "+v"(rot0), [r1] "+v"(rot1), \
+                     [sv] "=&s"(save)
+#define GS_ACC_Y_IN [m] "s"(mask), [m1] "s"(m1), [a] "v"(lds_addr), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), \
+                    [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
+    if constexpr (SECOND) {
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b128 %[q2], %[a] offset:32\n\t" GS_ACC_Y
+            : GS_ACC_Y_OUT, [q2] "+v"(q2)
+            : GS_ACC_Y_IN
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_andn2_b64 exec, %[m1], %[m]\n\t"
+            "ds_read_b128 %[q0], %[a]\n\t"
+            "ds_read_b128 %[q1], %[a] offset:16\n\t"
+            "ds_read_b32 %[q2], %[a] offset:32\n\t" GS_ACC_Y
+            : GS_ACC_Y_OUT, [q2] "+v"(q2.x)
+            : GS_ACC_Y_IN
+            : "memory", "scc");
+    }
+#undef GS_ACC_Y
+#undef GS_ACC_Y_OUT
+#undef GS_ACC_Y_IN
+#else
     // (SECOND: q2 = (b, r2, g2, b2), 16 bytes; otherwise only its first word is used: a 4-byte read, half the LDS cycles)
 #define GS_ACC_X                                     \
         "s_mov_b64 exec, %[m]\n\t"                   \
@@ -124,6 +192,9 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
         : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt),
           [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
         : "memory", "scc");
+    rot0 = ring_ror1(rot0);
+    rot1 = ring_ror1(rot1);
+#endif
 }
 
 // The per-entry values the inner loop reads, as the three 16-byte quads they are staged with in LDS:
@@ -195,7 +266,8 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
                                                         float4* __restrict__ qrows, uint32_t* __restrict__ q8,
                                                         const float4* __restrict__ ckpt,
                                                         const uint32_t* __restrict__ ck_start, const int chunks,
-                                                        const int blocks_per_chunk, const SecondImage second) {
+                                                        const int blocks_per_chunk, const SecondImage second,
+                                                        const L1Grad l1, const float l1_inv_n) {
     constexpr bool OPA = MODE == 1, SECOND = MODE == 2, SONES = MODE == 3;
     if constexpr (SECOND) { if (*second.all_ones != 0u) return; }
     if constexpr (SONES) { if (*second.all_ones == 0u) return; }
@@ -242,8 +314,19 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
         if (px < W && py < H) {
             const size_t HW = (size_t)H * W;
             const size_t pid = (size_t)py * W + px;
-            const float g0 = dL_dpix[pid], g1 = dL_dpix[HW + pid], g2 = dL_dpix[2 * HW + pid];
-            c0 = make_float4(g0, g1, g2, out_color[pid] * g0 + out_color[HW + pid] * g1 + out_color[2 * HW + pid] * g2);
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (dL_dpix) { g0 = dL_dpix[pid]; g1 = dL_dpix[HW + pid]; g2 = dL_dpix[2 * HW + pid]; }
+            const float o0 = out_color[pid], o1 = out_color[HW + pid], o2 = out_color[2 * HW + pid];
+            if (l1.target) {
+                // the fused L1 loss (GsFwdArgs.l1_target): d mean|out - target| / d out = sign(out - target) / (3 H W), times
+                // the loss's own gradient -- formed here instead of being written to and read from a gradient image
+                const float sc = (l1.grad ? l1.grad[0] : 1.0f) * l1_inv_n;
+                const float d0 = o0 - l1.target[pid], d1 = o1 - l1.target[HW + pid], d2 = o2 - l1.target[2 * HW + pid];
+                g0 += d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f);
+                g1 += d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
+                g2 += d2 > 0.f ? sc : (d2 < 0.f ? -sc : 0.f);
+            }
+            c0 = make_float4(g0, g1, g2, o0 * g0 + o1 * g1 + o2 * g2);
             const uint32_t nc = ncon_c[pid];
             c1.z = __uint_as_float((nc > (uint32_t)k0 ? nc - (uint32_t)k0 : 0u) + (uint32_t)j);
             // An image whose colours are all ONE -- the opacity channel o = (1 - Tf) + Tf bg, or a second render with
@@ -416,11 +499,9 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
             // X += ... on the lanes <= t (they have taken their entry of this round's chunk), Y += ... on the others
             // ... and the positions that take their entry at the next step read it meanwhile (none after the round's last step)
             const unsigned long long mx1 = (mx << 1) | 0x0001000100010001ull;
-            split_accumulate<SECOND>(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z, mx1, ea, cur.q0, cur.q1, cur.q2);
+            // ... and the pixel moves on to the next entry = the next lane: T and Rem rotate by one lane inside their ring
+            split_accumulate<SECOND>(X, Y, mx, Gd, dx, dy, tdx, tdy, wgt, g.x, g.y, g.z, mx1, ea, cur.q0, cur.q1, cur.q2, T, Rem);
             mx = mx1;
-            // the pixel moves on to the next entry = the next lane
-            T = ring_ror1(T);
-            Rem = ring_ror1(Rem);
         };
         // two steps per trip: the one-step-ahead pixel constants alternate between two register sets
         int t = 0;
@@ -451,24 +532,25 @@ __global__ __launch_bounds__(64, BWD_MIN_WAVES) void render_bwd_kernel(const flo
 int launch_render_backward(const float* rec, const uint32_t* ranges, const uint32_t* order, int W, int H,
                            const QuadLists& ql, const float* out_color, const float* dL_dpix, const float* dL_dopa,
                            const float* final_T, const float* bg, float* qrows, uint32_t* q8, const SecondImage* second,
-                           hipStream_t s) {
+                           L1Grad l1, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const int chunks = ql.ckpt ? ql.chunks : 1;
     const int bpc = render_grid_blocks(gx * gy, xmap);
     const dim3 grid((unsigned)bpc * (unsigned)chunks);
     const SecondImage none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const float l1_inv_n = 1.0f / (3.0f * (float)W * (float)H);
 #define GS_BWD_ARGS                                                                                                       \
     reinterpret_cast<const float4*>(rec), reinterpret_cast<const uint2*>(ranges), order, W, H, gx, gx * gy, xmap, ql.qlist, \
         ql.ncon_c, ql.qcount, out_color, dL_dpix, dL_dopa, final_T, bg, reinterpret_cast<float4*>(qrows), q8, ql.ckpt,    \
         ql.ck_start, chunks, bpc
     if (second) {
-        hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);  // (one of the two leaves at once)
-        hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second);
+        hipLaunchKernelGGL(render_bwd_kernel<2>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second, l1, l1_inv_n);  // (one of the two leaves at once)
+        hipLaunchKernelGGL(render_bwd_kernel<3>, grid, dim3(64), 0, s, GS_BWD_ARGS, *second, l1, l1_inv_n);
     } else if (dL_dopa)
-        hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);
+        hipLaunchKernelGGL(render_bwd_kernel<1>, grid, dim3(64), 0, s, GS_BWD_ARGS, none, l1, l1_inv_n);
     else
-        hipLaunchKernelGGL(render_bwd_kernel<0>, grid, dim3(64), 0, s, GS_BWD_ARGS, none);
+        hipLaunchKernelGGL(render_bwd_kernel<0>, grid, dim3(64), 0, s, GS_BWD_ARGS, none, l1, l1_inv_n);
 #undef GS_BWD_ARGS
     GS_LAUNCH_CHECK("render_backward", 0, s);
     return GS_OK;

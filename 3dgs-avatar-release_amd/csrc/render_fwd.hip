@@ -48,7 +48,15 @@ struct FwdArgs {
     // (a second render) the image state's word that says "this image IS 1 - T of the first render": this launch -- the one
     // that decides between compositing and leaving the speculative 1 - T image (common.h: second_ones_body) -- sets it
     uint32_t* __restrict__ all_ones;
+    // fused L1 loss (GsFwdArgs.l1_target; null: off): the target image and one partial sum of |out_color - target| per
+    // quadrant, written by the quadrant's wave(s) from the colours they hold at the end of their walk
+    const float* __restrict__ l1_target;
+    float* __restrict__ l1_part;
 };
+// |c - target| over the three channels of pixel `pid` (c = the composited colour, background included)
+__device__ __forceinline__ float l1_pixel(const FwdArgs& A, const size_t pid, const size_t HW, const float c0, const float c1, const float c2) {
+    return (fabsf(c0 - A.l1_target[pid]) + fabsf(c1 - A.l1_target[HW + pid])) + fabsf(c2 - A.l1_target[2 * HW + pid]);
+}
 __device__ __forceinline__ void forward_side_fill(const FwdArgs& A) {
     if (!A.marks) {  // not this launch's job; a state word it owns must not keep what an earlier use of the memory left there
         if (A.marks_flag && blockIdx.x == 0 && threadIdx.x == 0) *A.marks_flag = 0u;
@@ -256,6 +264,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         // chunks of the backward that never began
         if (chunks > 1 && lane > nck && lane < chunks) ck_start[(size_t)(tile * 4 + q) * (size_t)chunks + lane] = 0xFFFFFFFFu;
     }
+    float l1 = 0.f;
     if (inside) {
         const size_t HW = (size_t)H * W;
         const size_t pid = (size_t)py * W + px;
@@ -263,9 +272,15 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         final_T[pid] = Tf;
         n_contrib[pid] = FQ ? A.src_n_contrib[pid] : last;
         ncon_c[pid] = last_k;
-        out_color[pid] = C0 + Tf * bg[0];
-        out_color[HW + pid] = C1 + Tf * bg[1];
-        out_color[2 * HW + pid] = C2 + Tf * bg[2];
+        const float o0 = C0 + Tf * bg[0], o1 = C1 + Tf * bg[1], o2 = C2 + Tf * bg[2];
+        out_color[pid] = o0;
+        out_color[HW + pid] = o1;
+        out_color[2 * HW + pid] = o2;
+        if (A.l1_target) l1 = l1_pixel(A, pid, HW, o0, o1, o2);
+    }
+    if (A.l1_target) {  // (wave-uniform) the quadrant's share of the fused L1 loss, summed in the DPP ladder's fixed order
+        l1 = wave_sum(l1);
+        if (lane == 0) A.l1_part[tile * 4 + q] = l1;
     }
 }
 
@@ -305,6 +320,13 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t qperm(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
+// v * (value of `t` in the lane before, lane 0 of a quad: its own) as ONE instruction: the quad permute rides in the multiply
+// (left to the compiler, which folds the v_mov_dpp into the multiply and keeps the two wait states a DPP read of a value
+// just written needs; hand-written asm would have to carry its own s_nop)
+__device__ __forceinline__ float mul_qprev(float t, float v) {
+    const int i = __builtin_bit_cast(int, t);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x90, 0xF, 0xF, false)) * v;
+}
 #define QP_PREV 0x90   // quad_perm [0,0,1,2]: the lane before (lane 0 of the quad: itself)
 #define QP_PAIR 0x44   // quad_perm [0,1,0,1]
 #define QP_X1 0xB1     // quad_perm [1,0,3,2]
@@ -335,6 +357,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = lane >> 2, e = lane & 3;  // pixel of this wave (two rows of eight), entry slot of the step
     const bool e0 = e == 0;
+    const uint32_t e0_mask = e0 ? 0xFFFFFFFFu : 0u;
     const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
     const int px = QX0 + (p & 7), py = QY0 + 2 * wv + (p >> 3);
     const float pxf = (float)px, pyf = (float)py;
@@ -348,8 +371,14 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     const size_t quad = (size_t)(tile * 4 + q);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // T > 0 while the pixel is alive; frozen as -T (render_fwd_kernel).  The four lanes of a pixel hold the same T.
-    float T = inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;  // C: this lane's share of the pixel's colour
+    // Transmittance as TWO values (round 4; until then one, frozen as -T like render_fwd_kernel's): Tc, the running product
+    // T (1 - a) (1 - a') ... over EVERY entry evaluated so far, in list order -- it only ever decreases, so "the pixel is done"
+    // (an entry took it below 1e-4) is simply Tc < 1e-4, for good, and every later entry fails the test by itself -- and Tf,
+    // the value after the last entry that passed: final_T.  The sequential part of a step is then three multiplies (each
+    // with its quad permute folded in) instead of three rounds of permute + multiply + select, and the pass / freeze
+    // bookkeeping hangs off the chain instead of sitting on it.  The same multiplications in the same order as before: T,
+    // final_T, n_contrib, the recorded lists and the colours are bit for bit what the frozen-sign form produced.
+    float Tc = inside ? 1.0f : 0.0f, Tf = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;  // C: this lane's share of the pixel's colour
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;
     int nck = 0;
@@ -422,7 +451,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             s1 += qperm<QP_X2>(s1);
             s2 += qperm<QP_X2>(s2);
             nck = (int)(k0 / BWD_CH);  // (they come in order)
-            if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)(nck - 1)) * 64 + pix_q] = make_float4(fabsf(T), s0, s1, s2);
+            if (e0) ckpt[(quad * (size_t)(chunks - 1) + (size_t)(nck - 1)) * 64 + pix_q] = make_float4(Tc >= 0.0001f ? Tc : Tf, s0, s1, s2);
             if (tid == 0) ck_start[quad * (size_t)chunks + nck] = k0;
         };
         // the next chunk boundary this batch can meet (steps start at multiples of four: every c BWD_CH is a step boundary;
@@ -448,32 +477,31 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             const float G = __builtin_amdgcn_exp2f(power2);
             const float al = fminf(0.99f, b.y * G);
             const float a2 = (power2 <= 0.0f && al >= (1.0f / 255.0f)) ? al : 0.f;  // alpha, or 0 if the pair is rejected
-            // T before this lane's entry: T (1 - a2) of the lane before it, ... -- three rounds settle lanes 1, 2, 3
+            // T before this lane's entry: Tc times (1 - a2) of the lanes before it, multiplied up in list order -- three rounds
+            // settle lanes 1, 2, 3; lane 0 multiplies by 1 (its own value comes back from the permute)
             const float x = 1.f - a2;
-            const float xs = qperm<QP_PREV>(x);
-            float tb = T;
+            // (a bit select, one v_bfi: written as `e0 ? 1 : ...` the compiler branches around the permute)
+            const float xs = __uint_as_float((__float_as_uint(qperm<QP_PREV>(x)) & ~e0_mask) | (0x3F800000u & e0_mask));
+            float tb = Tc;
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const float t = qperm<QP_PREV>(tb) * xs;
-                tb = e0 ? T : t;
-            }
-            const float ta = tb * x;  // == tb for a rejected pair, < 0 for a frozen pixel
-            // blended iff this entry and every entry before it in the step pass the 1e-4 test
-            uint32_t ok = (ta >= 0.0001f) ? 0xFFFFFFFFu : 0u;
-            ok &= qperm<QP_PREV>(ok);
-            ok &= qperm<QP_PAIR>(ok);
-            const float w = __uint_as_float(__float_as_uint(a2 * tb) & ok);
+            for (int r = 0; r < 3; r++) tb = mul_qprev(tb, xs);
+            const float ta = tb * x;  // == tb for a rejected pair
+            // Tc only decreases: an entry passes the 1e-4 test exactly when it and every entry before it do
+            const bool pass = ta >= 0.0001f;
+            const float w = pass ? a2 * tb : 0.f;
             C0 += c.x * w;
             C1 += c.y * w;
             C2 += c.z * w;
             last_k = (w > 0.f) ? idx1 : last_k;
             idx1 += 4u;
-            // the pixel's T after the step: the last passing lane's, negated (frozen) unless all four passed.  (min over
-            // the bit patterns: all positive while alive, all equal once frozen)
-            uint32_t mag = (__float_as_uint(ta) & ok) | (__float_as_uint(T) & ~ok);
-            mag = min(mag, qperm<QP_X1>(mag));
-            mag = min(mag, qperm<QP_X2>(mag));
-            T = __uint_as_float(mag | (~qperm<QP_LAST>(ok) & 0x80000000u));
+            // final_T so far: the value after the last entry that passed (the passing lanes of a step are a prefix of the
+            // quad and their values decrease: the smallest one) -- off the sequential chain
+            // (positive floats order like their bit patterns: integer min, no NaN canonicalisation)
+            uint32_t cand = pass ? __float_as_uint(ta) : 0x7F800000u;
+            cand = min(cand, qperm<QP_X1>(cand));
+            cand = min(cand, qperm<QP_X2>(cand));
+            Tf = cand != 0x7F800000u ? __uint_as_float(cand) : Tf;
+            Tc = qperm<QP_LAST>(ta);  // the product over all four entries, in order
         };
         auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
         auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
@@ -508,7 +536,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             // its position in the TILE's list (n_contrib), looked up once per batch
             if (lk > kbase) last = __float_as_uint(srec[(lk - 1u - kstep0) * 3 + 2].w);
         }
-        const bool alive = __ballot(T > 0.f) != 0ull;
+        const bool alive = __ballot(Tc >= 0.0001f) != 0ull;
         if (lane == 0) s_flag[wv] = alive ? 1u : 0u;
         lds_barrier();
         live = (s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) != 0u;  // every pixel of the quadrant frozen: stop
@@ -524,16 +552,26 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     s0 += qperm<QP_X2>(s0);
     s1 += qperm<QP_X2>(s1);
     s2 += qperm<QP_X2>(s2);
+    float l1 = 0.f;
     if (inside && e0) {
         const size_t HW = (size_t)H * W;
         const size_t pid = (size_t)py * W + px;
-        const float Tf = fabsf(T);
         final_T[pid] = Tf;
         n_contrib[pid] = FQ ? A.src_n_contrib[pid] : last;
         ncon_c[pid] = last_k;
-        out_color[pid] = s0 + Tf * bg[0];
-        out_color[HW + pid] = s1 + Tf * bg[1];
-        out_color[2 * HW + pid] = s2 + Tf * bg[2];
+        const float o0 = s0 + Tf * bg[0], o1 = s1 + Tf * bg[1], o2 = s2 + Tf * bg[2];
+        out_color[pid] = o0;
+        out_color[HW + pid] = o1;
+        out_color[2 * HW + pid] = o2;
+        if (A.l1_target) l1 = l1_pixel(A, pid, HW, o0, o1, o2);
+    }
+    if (A.l1_target) {  // (workgroup-uniform) the four waves' shares, added in wave order
+        l1 = wave_sum(l1);
+        lds_barrier();  // (s_lastk has been read by thread 0)
+        if (lane == 0) s_lastk[wv] = __float_as_uint(l1);
+        lds_barrier();
+        if (tid == 0)
+            A.l1_part[quad] = (__uint_as_float(s_lastk[0]) + __uint_as_float(s_lastk[1])) + (__uint_as_float(s_lastk[2]) + __uint_as_float(s_lastk[3]));
     }
 }
 
@@ -566,7 +604,8 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const int xmap = gs_tune_get(GS_TUNE_XCD_MAP);
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
-                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag, ql.all_ones};
+                    ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag, ql.all_ones,
+                    ql.l1_target, ql.l1_part};
     const dim3 grid(render_grid_blocks(gx * gy, xmap));
     const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
@@ -579,6 +618,8 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
         else hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(64), 0, s, A);
     }
     GS_LAUNCH_CHECK("render_forward", 0, s);
+    if (ql.l1_target)  // the fused L1 loss: the quadrants' partial sums, added in index order, over the 3 H W elements
+        return launch_loss_final(ql.l1_part, gx * gy * 4, 1.0f / (3.0f * (float)W * (float)H), ql.l1_loss, s);
     return GS_OK;
 }
 

@@ -275,9 +275,15 @@ def _dump_snapshot(path, raster_settings, tensors):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, with_opacity=False):
+                        raster_settings, with_opacity=False, l1_target=None):
     """(color, radii), as upstream.  with_opacity=True (an extension; see GaussianRasterizer.forward) adds the
-    opacity render as a third result, computed and differentiated inside the same pass."""
+    opacity render as a third result, computed and differentiated inside the same pass; l1_target (an extension, too)
+    adds mean |color - l1_target| as the last result, computed by the render launch and differentiated in the
+    backward's own pixel prologue."""
+    if l1_target is not None:
+        l1_target = _f32c(l1_target, "l1_target")
+        if tuple(l1_target.shape) != (3, int(raster_settings.image_height), int(raster_settings.image_width)):
+            raise ValueError("diff_gaussian_rasterization: l1_target must be a (3, H, W) image")
     dep = None
     if (_FUSE_SECOND and _SHARE and not with_opacity and torch.is_grad_enabled() and colors_precomp is not None
             and colors_precomp.numel() and not colors_precomp.requires_grad and (sh is None or sh.numel() == 0)):
@@ -286,13 +292,15 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     if not _tls.grad_mode:
         # no_grad (the reference's render loop, render.py:51-62): no autograd node would be built, and Function.apply
         # costs ~10 us of Python per call for building none -- a tenth of a forward-only frame at 50k Gaussians
-        color, radii, opacity = _RasterizeGaussians.forward(_InferenceCtx(), means3D, means2D, sh, colors_precomp, opacities,
-                                                            scales, rotations, cov3Ds_precomp, raster_settings,
-                                                            bool(with_opacity), None)
-        return (color, radii, opacity) if with_opacity else (color, radii)
-    color, radii, opacity = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                       cov3Ds_precomp, raster_settings, bool(with_opacity), dep)
-    return (color, radii, opacity) if with_opacity else (color, radii)
+        color, radii, opacity, l1 = _RasterizeGaussians.forward(_InferenceCtx(), means3D, means2D, sh, colors_precomp, opacities,
+                                                                scales, rotations, cov3Ds_precomp, raster_settings,
+                                                                bool(with_opacity), None, l1_target)
+    else:
+        color, radii, opacity, l1 = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                                               rotations, cov3Ds_precomp, raster_settings, bool(with_opacity),
+                                                               dep, l1_target)
+    out = (color, radii, opacity) if with_opacity else (color, radii)
+    return out + (l1,) if l1_target is not None else out
 
 
 # The reference's render() rasterizes the opacity image with a second call on the same geometry, colours = constant ones
@@ -328,7 +336,7 @@ def _second_render_dependency(means3D, means2D, opacities, scales, rotations, co
 
 class _InferenceCtx(object):
     """What _forward / _finish touch of an autograd context, for a call under no_grad: nothing is saved, no node exists."""
-    needs_input_grad = (False,) * 11
+    needs_input_grad = (False,) * 12
 
     def set_materialize_grads(self, value):
         pass
@@ -343,15 +351,15 @@ class _InferenceCtx(object):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, with_opacity=False, dep=None):
+                raster_settings, with_opacity=False, dep=None, l1_target=None):
         if not raster_settings.debug:
             return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                cov3Ds_precomp, raster_settings, with_opacity, dep)
+                                                cov3Ds_precomp, raster_settings, with_opacity, dep, l1_target)
         # upstream's debug mode: the arguments are kept aside and written to snapshot_fw.dump if the native call fails
         args = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         try:
             return _RasterizeGaussians._forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                                cov3Ds_precomp, raster_settings, with_opacity, dep)
+                                                cov3Ds_precomp, raster_settings, with_opacity, dep, l1_target)
         except Exception:
             _dump_snapshot("snapshot_fw.dump", raster_settings, args)
             print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
@@ -359,8 +367,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                 raster_settings, with_opacity=False, dep=None):
+                 raster_settings, with_opacity=False, dep=None, l1_target=None):
         ctx.with_opacity = bool(with_opacity)
+        ctx.l1_target = None
+        l1 = None  # (never kept on ctx: an output held by its own node is a reference cycle around the whole saved state)
         ctx.defer_to = None
         means2D_in = means2D
         # outputs nothing downstream differentiates (always: radii) arrive as None in backward instead of as freshly
@@ -388,6 +398,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             capturing = _stream_capturing()
             if capturing:
                 a.frame_stats = None  # (a kernel storing into pinned host memory is not what a graph should replay)
+            if l1_target is not None:
+                # the fused L1 loss: its value is a by-product of the render launch, its gradient of the backward's prologue
+                ctx.l1_target = l1_target
+                l1 = torch.empty((), dtype=torch.float32, device=dev)
+                a.l1_target, a.l1_loss = l1_target.data_ptr(), l1.data_ptr()
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
             # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
@@ -395,8 +410,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream_h,
                                     capturing)
                     if share else None)
-            hit = _geom_cache.take(dev, gkey) if share else None
-            if not share:
+            hit = _geom_cache.take(dev, gkey) if (share and l1_target is None) else None  # (a shared-geometry render has no fused loss)
+            if not share or l1_target is not None:
                 _geom_cache.offer.pop(dev.index, None)
             ctx.geom_entry = None
             if hit is not None:
@@ -465,7 +480,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _geom_cache.put(dev, ctx.geom_entry)
                 return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                    opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img,
-                                                   color, dev, a, sptr, keep)
+                                                   color, dev, a, sptr, keep, l1)
             count = _pinned_count(dev)
             # The binning state is sized by the pair count, which only phase 1 produces.  A buffer for the
             # previous frame's count (+ 1/8) is handed to gs_forward, which enqueues phase 2 right behind phase 1
@@ -501,11 +516,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _geom_cache.put(dev, ctx.geom_entry)
             return _RasterizeGaussians._finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp,
                                                opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, img, color,
-                                               dev, a, sptr, keep)
+                                               dev, a, sptr, keep, l1)
 
     @staticmethod
     def _finish(ctx, raster_settings, num_rendered, capacity, means3D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr, keep=None):
+                cov3Ds_precomp, radii, geom, binning, img, color, dev, a, sptr, keep=None, l1=None):
         opacity = None
         if ctx.with_opacity:
             # the opacity render is (1 - final_T) + final_T * bg[0]: the forward that just ran holds final_T
@@ -525,21 +540,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                               scales if scales is not None else empty, rotations if rotations is not None else empty,
                               cov3Ds_precomp if cov3Ds_precomp is not None else empty, radii, geom, binning, img, color)
         ctx.mark_non_differentiable(radii)
-        return color, radii, opacity
+        return color, radii, opacity, l1
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
+    def backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None, grad_l1=None):
         if not ctx.raster_settings.debug:
-            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity)
+            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity, grad_l1)
         try:
-            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity)
+            return _RasterizeGaussians._backward(ctx, grad_out_color, _grad_radii, grad_out_opacity, grad_l1)
         except Exception:
             _dump_snapshot("snapshot_bw.dump", ctx.raster_settings, tuple(ctx.saved_tensors[:8]) + (grad_out_color,))
             print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
             raise
 
     @staticmethod
-    def _backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None):
+    def _backward(ctx, grad_out_color, _grad_radii, grad_out_opacity=None, grad_l1=None):
         L = _lib.load()
         tgt = getattr(ctx, "defer_to", None)
         if tgt is not None and tgt.geom is not None and grad_out_color is not None:
@@ -548,7 +563,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             saved = ctx.saved_tensors
             tgt.second = dict(colors=saved[2], out_color=saved[11], grad=_f32c(grad_out_color, "grad_out_color"), img=saved[10],
                               long_lists=ctx.long_lists)
-            return (None,) * 11
+            return (None,) * 12
         entry = getattr(ctx, "geom_entry", None)
         second = None
         if entry is not None:  # a render after this backward (e.g. after an optimiser step) must not meet this state
@@ -563,9 +578,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         W, H = int(settings.image_width), int(settings.image_height)
         D = ctx.capacity
-        if grad_out_color is None:  # only the opacity render was used downstream
+        use_l1 = ctx.l1_target is not None and grad_l1 is not None
+        if grad_out_color is None and not use_l1:  # only the opacity render was used downstream
             grad_out_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
-        g = _f32c(grad_out_color, "grad_out_color")
+        g = _f32c(grad_out_color, "grad_out_color") if grad_out_color is not None else None
+        g_l1 = _f32c(grad_l1, "grad_l1") if use_l1 else None
         g_op = _f32c(grad_out_opacity, "grad_out_opacity") if (ctx.with_opacity and grad_out_opacity is not None) else None
         with _lib.on_device(dev):
             a, _keep = ctx.fwd_args  # the forward's argument block: the same tensors (saved above), the same long_lists
@@ -576,6 +593,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 a = _make_args(settings, means3D, sh if has_sh else None, colors_precomp if has_col else None, opacities,
                                scales if has_sr else None, rotations if has_sr else None,
                                cov3Ds_precomp if has_cov else None, _keep, long_lists=ctx.long_lists)
+            # the fused L1 loss: dL/d(image) of it is formed per pixel inside the backward's render pass (no gradient image)
+            a.l1_target = ctx.l1_target.data_ptr() if use_l1 else None
+            a.l1_loss = None  # (the forward's output; the backward does not touch it)
+            a.l1_grad = g_l1.data_ptr() if use_l1 else None
+            gp = g.data_ptr() if g is not None else None
             sptr = _lib.stream_ptr(dev)
             scratch_bytes = _size("gs_backward_scratch_bytes", D, P, W, H)
             scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
@@ -596,21 +618,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                                         second["img"].data_ptr(), second["img"].numel(), int(second["long_lists"]))
                 _lib.check(L.gs_backward_with_second(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
                                                      binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
-                                                     color.data_ptr(), g.data_ptr(), ctypes.byref(si), scratch.data_ptr(),
+                                                     color.data_ptr(), gp, ctypes.byref(si), scratch.data_ptr(),
                                                      scratch_bytes, ctypes.byref(gr), sptr))
             elif g_op is None:
                 _lib.check(L.gs_backward(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
                                          binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
-                                         color.data_ptr(), g.data_ptr(), scratch.data_ptr(), scratch_bytes,
+                                         color.data_ptr(), gp, scratch.data_ptr(), scratch_bytes,
                                          ctypes.byref(gr), sptr))
             else:
                 # the opacity render's gradient rides along as a fourth channel of the same backward pass
                 _lib.check(L.gs_backward_with_opacity(ctypes.byref(a), radii.data_ptr(), geom.data_ptr(), geom.numel(),
                                                       binning.data_ptr(), binning.numel(), img.data_ptr(), img.numel(), D,
-                                                      color.data_ptr(), g.data_ptr(), g_op.data_ptr(), scratch.data_ptr(),
+                                                      color.data_ptr(), gp, g_op.data_ptr(), scratch.data_ptr(),
                                                       scratch_bytes, ctypes.byref(gr), sptr))
         return (d_means3D, d_means2D, d_sh, d_colors if has_col else None, d_opacity, d_scales, d_rot,
-                d_cov3D if has_cov else None, None, None, None)
+                d_cov3D if has_cov else None, None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -634,10 +656,14 @@ class GaussianRasterizer(nn.Module):
         return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, with_opacity=False):
+                cov3D_precomp=None, with_opacity=False, l1_target=None):
         """Upstream signature and results: (color[3,H,W], radii[N]).  `with_opacity=True` is an extension: a third
         result, the opacity render [1,H,W] -- what the reference gets from a second call with colours = 1
-        (gaussian_renderer/__init__.py:132-142, `[:1]`) -- produced and differentiated inside the same pass."""
+        (gaussian_renderer/__init__.py:132-142, `[:1]`) -- produced and differentiated inside the same pass.
+        `l1_target` (a (3,H,W) image) is an extension, too: a LAST result, the scalar mean |color - l1_target| -- the
+        reference's `l1_loss(image, gt_image)` (train.py:121, utils/loss_utils.py:21-22) -- computed by the render launch
+        from the colours it has just composited; its gradient w.r.t. the image is formed per pixel inside the backward
+        (added to whatever gradient `color` itself receives), so no gradient image is written or read for it."""
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -655,4 +681,4 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings, with_opacity=with_opacity)
+                                   raster_settings, with_opacity=with_opacity, l1_target=l1_target)

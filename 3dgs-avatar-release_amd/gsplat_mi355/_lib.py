@@ -18,7 +18,7 @@ class GsFwdArgs(ctypes.Structure):
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("campos", c_void_p),
         ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
         ("prefiltered", c_int32), ("debug", c_int32), ("tile_rect", c_int32), ("long_lists", c_int32),
-        ("frame_stats", c_void_p),
+        ("frame_stats", c_void_p), ("l1_target", c_void_p), ("l1_loss", c_void_p), ("l1_grad", c_void_p),
     ]
 
 
@@ -38,7 +38,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
-           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second"]
+           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second", "gs_clock_probe", "gs_pair_stats"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_E_CAPTURE = -6
@@ -113,6 +113,9 @@ def load():
         L.gs_geom_field.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        L.gs_clock_probe.argtypes = [c_void_p, c_int32, c_void_p]
+        L.gs_pair_stats.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_int64, c_void_p,
+                                    c_void_p]
         L.gs_tuning.argtypes = [c_char_p, c_int]
         L.gs_profile_reserve.argtypes = [c_int]
         L.gs_profile_enable.argtypes = [c_int]
@@ -161,6 +164,16 @@ def profile_collect(max_stages=32):
     n = c_int32(0)
     check(load().gs_profile_collect(max_stages, names, ms, cnt, ctypes.byref(n)))
     return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
+
+
+def clock_probe(dev, iters=8192):
+    """Shader clock in Hz under a VALU-bound load (an FMA stream of ~1 ms on every SIMD), measured now on `dev`."""
+    import torch
+    t = torch.zeros(4, dtype=torch.int64, device=dev)
+    with on_device(dev):
+        check(load().gs_clock_probe(t.data_ptr(), int(iters), stream_ptr(dev)))
+    c = t.cpu()
+    return float(c[0]) / max(float(c[1]), 1.0) * 1.0e8
 
 
 def nbytes(fn, *args):

@@ -47,7 +47,11 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
         color = torch.zeros(3, H, W, device=dev)
         _lib.check(L.gs_forward_render(ctypes.byref(a), geom.data_ptr(), gb, binning.data_ptr(), bb, img.data_ptr(), ib,
                                        D, color.data_ptr(), sptr))
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        _lib.check(L.gs_pair_stats(ctypes.byref(a), geom.data_ptr(), gb, binning.data_ptr(), bb, img.data_ptr(), ib, D,
+                                   counts.data_ptr(), sptr))
         stream.synchronize()
+        pairs_valid, pairs_walked = (int(v) for v in counts.cpu())
 
         def field(fn, *args):
             out = ctypes.c_void_p(0)
@@ -81,13 +85,15 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
     ok = int(lens.sum()) == D and (starts.size == 0 or (starts[0] == 0 and np.array_equal(starts[1:], r[nz, 1][:-1])))
     # (consistent only if the non-empty ranges tile [0, D) in tile order; otherwise a pattern no comparison accepts)
     b["tile_ids"] = np.repeat(np.arange(r.shape[0], dtype=np.uint32), lens) if ok else np.full(D, 0xFFFFFFFF, np.uint32)
-    return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im)
+    return dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), D=D, geom=g, binning=b, image=im,
+                pairs_valid=pairs_valid, pairs_walked=pairs_walked)
 
 
 def frame_stats(cam, cloud, pipe, bg):
-    """(num_rendered D, mean n_contrib per pixel, quadrant hits) of one frame: reported beside every benchmark number.
-    Quadrant hits = (8x8 quadrant, Gaussian) entries up to each quadrant's last contributor: what the backward's wave
-    per quadrant iterates over, 64 pixels per entry."""
+    """(num_rendered D, mean n_contrib per pixel, quadrant hits, pairs composited) of one frame: reported beside every
+    benchmark number.  Quadrant hits = (8x8 quadrant, Gaussian) entries up to each quadrant's last contributor: what the
+    backward's wave per quadrant iterates over, 64 pixels per entry; pairs composited = the (pixel, Gaussian) pairs with
+    alpha >= 1/255 before the pixel is done (gs_pair_stats): the useful part of 64 x quadrant hits."""
     import math
     settings = GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
@@ -97,4 +103,5 @@ def frame_stats(cam, cloud, pipe, bg):
     with torch.no_grad():
         st = forward_state(settings, cloud.xyz.detach(), cloud.opacity.detach(), shs=cloud.shs.detach(),
                            scales=cloud.scales.detach(), rotations=cloud.rotations.detach())
-    return int(st["D"]), float(st["image"]["n_contrib"].mean()), int(st["image"]["qcount"].astype("int64").sum())
+    return (int(st["D"]), float(st["image"]["n_contrib"].mean()), int(st["image"]["qcount"].astype("int64").sum()),
+            int(st["pairs_valid"]))

@@ -63,11 +63,14 @@ def _zero_leaf(like):
     return z.detach().requires_grad_(True)
 
 
-def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, return_opacity=False):
+def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, return_opacity=False, l1_target=None):
     """data: camera (FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
     camera_center); pc: tensors named as GaussianModel's getters (xyz, opacity, scales, rotations, shs).
     If `colors_precomp` is given it is used (the reference always does: gaussian_renderer/__init__.py:117-124);
-    otherwise SHs are handed to the rasterizer for in-kernel SH->RGB (north_star)."""
+    otherwise SHs are handed to the rasterizer for in-kernel SH->RGB (north_star).
+    `l1_target` (not a reference argument): the ground-truth image; the package then carries `l1` = mean |render -
+    l1_target|, the reference's `l1_loss(image, gt_image)` (train.py:121), computed and differentiated inside the
+    rasterizer's own launches (GaussianRasterizer.forward, `l1_target`)."""
     xyz = pc.xyz
     # gaussian_renderer/__init__.py:76-80 builds `zeros_like(xyz, requires_grad=True) + 0` and retains its gradient: a
     # tensor whose only purpose is to receive dL/dmeans2D in `.grad`.  A zero LEAF does that with one fill launch instead
@@ -99,15 +102,18 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
                                 fwd_transform=getattr(pc, "fwd_transform", None))
     shs = None if colors_precomp is not None else pc.shs
     opacity_image = None
+    l1 = None
     if return_opacity and getattr(pipe, "fuse_opacity", False):
-        rendered_image, radii, opacity_image = rasterizer(means3D=means3D, means2D=means2D, shs=shs,
-                                                          colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-                                                          rotations=rotations, cov3D_precomp=cov3D_precomp,
-                                                          with_opacity=True)
+        res = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, with_opacity=True,
+                         l1_target=l1_target)
+        rendered_image, radii, opacity_image = res[:3]
     else:
-        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                           opacities=opacity, scales=scales, rotations=rotations,
-                                           cov3D_precomp=cov3D_precomp)
+        res = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, l1_target=l1_target)
+        rendered_image, radii = res[:2]
+    if l1_target is not None:
+        l1 = res[-1]
     if return_opacity and opacity_image is None:
         opacity_image, _ = rasterizer(means3D=means3D, means2D=means2D, shs=None,
                                       colors_precomp=torch.ones(opacity.shape[0], 3, device=opacity.device),
@@ -115,7 +121,7 @@ def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, 
                                       cov3D_precomp=cov3D_precomp)
         opacity_image = opacity_image[:1]
     return RenderPackage(deformed_gaussian=pc, render=rendered_image, viewspace_points=screenspace_points,
-                         radii=radii, opacity_render=opacity_image)
+                         radii=radii, opacity_render=opacity_image, l1=l1)
 
 
 class _L1Loss(torch.autograd.Function):
@@ -261,13 +267,14 @@ class DensifyStats(object):
         densify_stats(pkg.radii, pkg.viewspace_points.grad, self.max_radii2D, self.xyz_gradient_accum, self.denom)
 
 
-def train_step(data, pc, pipe, bg_color, gt_image, gt_mask=None, lambda_mask=0.0, stats=None):
+def train_step(data, pc, pipe, bg_color, gt_image, gt_mask=None, lambda_mask=0.0, stats=None, fuse_l1=False):
     """One forward+backward of the rasterizer part of the reference's train step: L1 image loss
     (train.py:121), optional L1 mask loss on the opacity render (train.py:143-153), .backward()
-    (train.py:179), densification statistics (train.py:219-220)."""
+    (train.py:179), densification statistics (train.py:219-220).  fuse_l1: the image loss comes out of the rasterizer
+    itself (render(..., l1_target=gt_image)) instead of a loss call on the rendered image."""
     use_mask = lambda_mask > 0.0 and gt_mask is not None
-    pkg = render(data, pc, pipe, bg_color, return_opacity=use_mask)
-    loss = l1_loss(pkg.render, gt_image)
+    pkg = render(data, pc, pipe, bg_color, return_opacity=use_mask, l1_target=gt_image if fuse_l1 else None)
+    loss = pkg.l1 if fuse_l1 else l1_loss(pkg.render, gt_image)
     if use_mask:
         loss = loss + lambda_mask * l1_loss(pkg.opacity_render, gt_mask)
     loss.backward()

@@ -47,7 +47,6 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (spec)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD-32 for 2 cycles
-MEASURED_VALU_CLOCK_HZ = 2.07e9  # shader clock under a VALU-bound kernel (see roofline.binding)
 
 WORKLOADS = {
     # name: (N, W, H, sh_degree, heavy_tail, backward)
@@ -96,6 +95,11 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--loss", default="l1", choices=["l1", "l1+dssim"],
                     help="l1 = the BASELINE metric's loss; l1+dssim = 0.8 L1 + 0.2 (1 - SSIM), the reference's full image loss")
+    ap.add_argument("--l1", default="fused", choices=["fused", "separate"],
+                    help="where the L1 image loss is computed: fused = inside the rasterizer's own launches (render(..., "
+                         "l1_target=gt): value from the render launch, gradient formed in the backward's pixel prologue, no "
+                         "gradient image); separate = gsplat_mi355.render.l1_loss on the rendered image (its own two "
+                         "launches, a gradient image written and read), the reference's call pattern at train.py:121")
     ap.add_argument("--prepass", action="store_true",
                     help="the reference's avatar call pattern: covariance from scaling + rotation_precomp (3x3) and colours "
                          "from SHs in the canonical frame computed BEFORE the rasterizer (fused N3 ops), passed as "
@@ -194,6 +198,27 @@ def pmc_passes(args, argv):
     return res, "rocprofv3 --pmc child passes of this command (%s), mean per launch" % " | ".join(",".join(c) for c in PMC_PASSES)
 
 
+def pin_rank_to_cores(local_rank, local_world):
+    """One rank = one Python loop issuing a frame every 0.2-0.6 ms + autograd's backward thread: a rank that migrates or
+    shares its cores with seven others stalls its GPU (the pair-count wait lets the host run one frame ahead at most:
+    DESIGN.md 1).  Gives rank r of the node the r-th contiguous slice of the cores this process may run on -- before
+    anything touches the GPU -- and returns "first-last (count)", or None where affinity cannot be set or
+    GSPLAT_BENCH_NO_AFFINITY=1 says not to."""
+    if os.environ.get("GSPLAT_BENCH_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity") or local_world < 1:
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 2:  # fewer than two cores per rank: leave the scheduler alone
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(per, 8)))
+        return "%d-%d (%d cores)" % (mine[0], mine[-1], len(mine))
+    except OSError:
+        return None
+
+
 def frame_plan(rank, world, steps, warmup, total_frames=0):
     """(frames this rank renders, in order; K = how many of them the timed region covers).  The first 8 + warmup frames are
     rendered before the timed region (first touches, settle, warm-up), the last K inside it.
@@ -234,6 +259,7 @@ def main(argv=None):
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
 
     pmc, pmc_note = {}, "skipped (--no-pmc)"
     if world == 1 and not args.pmc_child and not args.no_pmc:
@@ -241,7 +267,10 @@ def main(argv=None):
 
     rehearsal = False
     dist = None
-    if world > 1:
+    # GSPLAT_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, broadcast, checksums, barriers, max over
+    # ranks) also with ONE rank -- tests/test_gpu_bench.py runs the RCCL backend that way on a one-GPU box
+    use_dist = world > 1 or os.environ.get("GSPLAT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -274,14 +303,14 @@ def main(argv=None):
     cloud = synthetic_cloud(N, sh_degree=deg, seed=0, heavy_tail=tail, device=dev,
                             layout=WORKLOAD_LAYOUT.get(args.workload, "box")) if rank == 0 else None
     t_bcast = 0.0
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cloud = broadcast_cloud(cloud, N, deg, dev, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     state_sums = None
-    if world > 1:
+    if use_dist:
         # evidence that every rank renders the SAME Gaussian state: a checksum of the packed buffer's bit patterns per rank
         cs = cloud.pack().view(torch.int32).to(torch.int64).sum().reshape(1)
         if rehearsal:
@@ -338,8 +367,9 @@ def main(argv=None):
         if args.prepass:
             cloud.rotation_precomp.grad = None
         if do_bwd:
-            pkg = render(cams[i], cloud, pipe, bg, return_opacity=(args.opacity != "none"))
-            loss = l1_loss(pkg.render, gt)
+            fused = args.l1 == "fused"
+            pkg = render(cams[i], cloud, pipe, bg, return_opacity=(args.opacity != "none"), l1_target=gt if fused else None)
+            loss = pkg.l1 if fused else l1_loss(pkg.render, gt)
             if args.opacity != "none":
                 loss = loss + 0.1 * l1_loss(pkg.opacity_render, gt_mask)
             if args.loss == "l1+dssim":  # train.py:120-124 with lambda_l1 = 0.8, lambda_dssim = 0.2
@@ -384,7 +414,7 @@ def main(argv=None):
         # D and n_contrib of the benchmark frame (reported with every number: cost is a function of D)
         with torch.no_grad():
             vis = int((pkg.radii > 0).sum().item())
-        D, mean_contrib, quad_hits = frame_stats(cams[0], cloud, pipe, bg)
+        D, mean_contrib, quad_hits, pairs_valid = frame_stats(cams[0], cloud, pipe, bg)
         # untimed: ~0.7 s of back-to-back steps right before the warm-up, so that the chip's clocks have settled under
         # THIS load (the statistics above leave the GPU idle for a while; a timed region that starts on an idle chip
         # reads 10-25 % slow for its first hundreds of steps), then the W warm-up steps and the K timed ones
@@ -413,7 +443,7 @@ def main(argv=None):
             step(8 + i)
         torch.cuda.synchronize()
         _lib.profile_collect()  # returns every event used so far to the pool: the timed loop takes them from there
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -435,11 +465,14 @@ def main(argv=None):
                     tile_rect, i + 1, (time.perf_counter() - t0) / (i + 1) * 1e3, st["reserved_bytes.all.current"] / 1e6,
                     st["allocation.all.allocated"], st["num_ooms"], dgr._last_count.get((dev.index, N, W, H))), file=sys.stderr, flush=True)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         gc.enable()
+        # the shader clock the chip holds under a VALU-bound load, measured NOW, right behind the timed loop (an FMA stream
+        # of ~1 ms on every SIMD: s_memtime against the constant 100 MHz counter) -- for roofline.binding
+        clock_hz = _lib.clock_probe(dev) if world == 1 else None
         dom = _lib.profile_collect().get(dominant, (0.0, 0))
         _lib.profile_enable(False)
         # Per-stage times, taken NOW: right behind the timed loop, on the same settled clocks and over the same frames, one
@@ -456,7 +489,7 @@ def main(argv=None):
                 post[name] = got[0] / 8.0  # ms per frame (a stage may run more than once per frame)
         _lib.profile_enable(False)
         stage_ms = post or stage_ms
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -474,19 +507,24 @@ def main(argv=None):
             if st not in in_groups:
                 grouped[st] = v
         # what the step spends outside the library's stages: torch glue launches (autograd's ones-fill, grad * g, the
-        # zero leaf), gaps between kernels, host pacing -- so that the entries add up to ms_per_step
-        grouped["outside_stages"] = max(ms_step - sum(grouped.values()), 0.0) if world == 1 else 0.0
+        # zero leaf), gaps between kernels, host pacing.  DERIVED, not measured: ms_per_step (the timed loop) minus the
+        # stage times (8 frames per stage, taken right behind the loop) -- it can come out slightly negative when the
+        # stage passes read a little long; the signed value is reported, `stages_ms` carries it clamped at 0 so that the
+        # entries add up to ms_per_step.  Not formed for world > 1 (the step time there is the slowest rank's).
+        residual = ms_step - sum(grouped.values())
+        grouped["outside_stages"] = max(residual, 0.0) if world == 1 else 0.0
         stage_frac = {g: round(sb[g] / (grouped[g] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for g in sb if grouped.get(g, 0.0) > 0}
         return {
             "fps": total_frames / elapsed, "ms_per_step": ms_step, "elapsed": elapsed, "D": D, "visible": vis, "K": K,
             "stages_frac": stage_frac,
-            "mean_contrib": mean_contrib, "quad_hits": quad_hits, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
+            "mean_contrib": mean_contrib, "quad_hits": quad_hits, "pairs_valid": pairs_valid, "dominant": dominant, "dom_ms": dom_ms, "stage_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": sb[dominant],
                          "frame_algorithmic_bytes": frame_bytes,
                          "frame_frac": round(frame_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {g: round(v, 4) for g, v in grouped.items()},
+            "outside_stages_signed": round(residual, 4) if world == 1 else None, "stage_pass_frames": 8, "clock_hz": clock_hz,
         }
 
     default_rect = int(os.environ.get("GSPLAT_TILE_RECT", "1"))
@@ -522,6 +560,10 @@ def main(argv=None):
             if ms <= 0:
                 continue
             rec = {"kernel_ms": round(ms, 4), "pairs_evaluated": pairs_eval,
+                   # pairs actually composited (alpha >= 1/255 before the pixel is done; gs_pair_stats, outside the timed
+                   # region) and their share of what the kernel evaluates: the head-room finer culling than 8 x 8 could have
+                   "pairs_valid": float(main_leg["pairs_valid"]),
+                   "pairs_valid_over_evaluated": round(main_leg["pairs_valid"] / max(pairs_eval, 1.0), 4),
                    "flops_8d": fl[stage], "tflops_8d": round(fl[stage] / (ms * 1e-3) / 1e12, 2),
                    "frac_of_fp32_vector_peak": round(fl[stage] / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
             insts = per_kernel.get(kname, {}).get("valu_insts")
@@ -534,11 +576,13 @@ def main(argv=None):
             # the ceiling that actually binds the dominant kernel, next to the HBM one the contract asks for
             roof["binding"] = {"ceiling": "VALU issue slots (one wave64 instruction per SIMD-32 every 2 cycles)",
                                "frac": valu[dominant]["issue_slot_util"], "kernel": dominant,
-                               # the chip does not hold 2.4 GHz under a VALU-bound load: s_memtime against s_memrealtime
-                               # reads 2.07 GHz in an FMA stream and in the forward's loop (tools/valu_rate.hip,
-                               # tools/fwd_two_pixel.hip; a builder-measured constant, not taken live)
-                               "measured_clock_hz": MEASURED_VALU_CLOCK_HZ,
-                               "frac_at_measured_clock": round(valu[dominant]["issue_slot_util"] * CLOCK_HZ / MEASURED_VALU_CLOCK_HZ, 4)}
+                               # the chip does not hold 2.4 GHz under a VALU-bound load: measured live in this run, right
+                               # behind the timed loop (gs_clock_probe: an FMA stream of ~1 ms on every SIMD, s_memtime
+                               # against s_memrealtime)
+                               "measured_clock_hz": main_leg["clock_hz"],
+                               "clock_source": "gs_clock_probe behind the timed loop of this run",
+                               "frac_at_measured_clock": (round(valu[dominant]["issue_slot_util"] * CLOCK_HZ / main_leg["clock_hz"], 4)
+                                                          if main_leg.get("clock_hz") else None)}
         roof["valu"] = {"peak_tflops": VALU_PEAK_TFLOPS, "simds": SIMDS, "clock_hz": CLOCK_HZ,
                         "note": "secondary ceiling (SURVEY.md 8d): the render kernels are VALU-issue bound, not HBM bound; "
                                 "issue_slot_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
@@ -555,14 +599,16 @@ def main(argv=None):
             "config": {"workload": "%s: %dk Gaussians, %dx%d, SH deg %d, %s; shs+scales+rotations inputs, %s" % (
                 args.workload, N // 1000, W, H, deg, "forward+backward" if do_bwd else "forward",
                 ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 D-SSIM loss") +
+                (" (L1 fused into the rasterizer: l1_target)" if (do_bwd and args.l1 == "fused") else "") +
                 (", covariance + colours precomputed by the fused pre-pass" if args.prepass else "") +
                 (", + densification statistics + Adam step" if args.train_step else "") +
                 ("" if args.opacity == "none" else ", + opacity render (%s) with 0.1 L1 mask loss" % args.opacity)),
-                "tile_rect": default_rect, "gaussians": N, "visible": main_leg["visible"], "width": W, "height": H,
+                "tile_rect": default_rect, "l1": (args.l1 if do_bwd else None), "long_lists": dgr._LONG_LISTS, "gaussians": N, "visible": main_leg["visible"], "width": W, "height": H,
                 "sh_degree": deg, "num_rendered": main_leg["D"], "mean_n_contrib": round(main_leg["mean_contrib"], 2),
                 "frames_per_rank": ([args.total_frames // world, (args.total_frames + world - 1) // world] if strong else K),
                 "total_frames": args.total_frames if strong else world * K, "ranks": world,
-                "backend": "none" if world == 1 else ("gloo (REHEARSAL: all ranks on one GPU)" if rehearsal else "nccl (RCCL)"),
+                "backend": "none" if not use_dist else ("gloo (REHEARSAL: all ranks on one GPU)" if rehearsal else "nccl (RCCL)"),
+                "rank_cpu_affinity": affinity,
                 "parallelism": "frames sharded x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
                 "broadcast_s": round(t_bcast, 6), "state_checksums": state_sums},
             "roofline": roof,
@@ -571,6 +617,8 @@ def main(argv=None):
             "stages_ms": main_leg["stages_ms"],
             "stages_frac": main_leg["stages_frac"],
             "stages_detail_ms": {k: round(v, 4) for k, v in sorted(main_leg["stage_ms"].items())},
+            # `outside_stages` is derived (ms_per_step - sum of the stage times), clamped at 0 in stages_ms; the signed residual:
+            "outside_stages_derived": {"signed_ms": main_leg["outside_stages_signed"], "stage_pass_frames": main_leg["stage_pass_frames"]},
         }
         if up_leg is not None:
             # the reference's own binning (3-sigma squares): tile lists / ranges / num_rendered are upstream's bit for bit
@@ -583,7 +631,7 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cloud, W, H, deg, gt, do_bwd, args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -94,6 +94,17 @@ typedef struct GsFwdArgs {
     int64_t* frame_stats; /* NULL, or two words the forward writes (device-visible host memory or device memory), for the
                           * caller to choose long_lists for the NEXT frame: [0] tiles whose list is long against this
                           * frame's total (the tiles the four-wave forward takes), [1] the longest tile list */
+    /* ---- L1 image loss fused into the rasterizer (train.py:121 `Ll1 = l1_loss(image, gt_image)`,
+     * utils/loss_utils.py:21-22).  l1_target (NULL = off): the target image [3,H,W].  The forward's render launch then also
+     * adds up |out_color - l1_target| over the pixels it has just composited and l1_loss[0] (device float, required with
+     * l1_target) receives the mean over the 3 H W elements -- the image is not read again.  The backward (the same
+     * argument block) forms dL/d out_color of that loss itself, per pixel, in the prologue of its render pass:
+     * sign(out_color - l1_target) / (3 H W) times l1_grad[0] (device float = dLoss/d l1_loss; NULL = 1), ADDED to the
+     * dL_dpix the caller passes (which may then be NULL) -- no gradient image is written or read.  Supported by
+     * gs_forward / gs_forward_render and every gs_backward*; gs_forward_shared ignores it. */
+    const float* l1_target;
+    float* l1_loss;
+    const float* l1_grad;
 } GsFwdArgs;
 
 /* The eight gradient outputs of upstream `rasterize_gaussians_backward`, in the order the
@@ -164,7 +175,8 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
                       float* out_color, void* stream);
 
 /* ---- backward (replaces upstream rasterize_gaussians_backward).  `out_color` is the forward's
- * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W].  `num_rendered` is the number of
+ * output image, `radii` the forward's radii, `dL_dpix` = dL/d out_color [3,H,W] (NULL allowed when a->l1_target is set: the
+ * fused L1 loss is then the only consumer of the image).  `num_rendered` is the number of
  * pairs the forward's binning state was carved for (the capacity given to gs_forward, or the count given to
  * gs_forward_render).  `scratch` holds gs_backward_scratch_bytes(num_rendered, P, W, H) bytes.
  * The binning state also holds the mark word of every gradient row the backward writes (all "unwritten" on entry): the
@@ -325,6 +337,20 @@ int gs_profile_reserve(int n_events); /* pre-create events so that none is creat
 int gs_profile_enable(int on);
 int gs_profile_filter(const char* stage); /* NULL or "" = every stage; else only the named stage is timed */
 int gs_profile_collect(int max, const char** names, float* ms, int32_t* launches, int32_t* n_out);
+
+/* Report counter (bench.py's `pairs_valid`; never in a timed path): from the state of a finished forward, counts[0] = the
+ * (pixel, Gaussian) pairs actually composited -- alpha >= 1/255 at that pixel, before the pixel was done -- and counts[1] =
+ * the pairs a per-pixel walk up to each pixel's last contributor visits (the sum of n_contrib).  `counts`: two device
+ * uint64.  Against 64 x (quadrant-list entries up to each quadrant's last contributor), which is what the render kernels
+ * evaluate, counts[0] says how much of their work is useful. */
+int gs_pair_stats(const GsFwdArgs* a, const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                  const void* img, size_t img_bytes, int64_t num_rendered, uint64_t* counts, void* stream);
+
+/* Shader clock under load (bench.py's `roofline.binding`): runs an FMA stream on every SIMD for `iters` x 32 instructions per
+ * wave (8192 iterations ~ 1 ms) and adds up, over the workgroups, ticks[0] = shader-clock cycles (s_memtime) and ticks[1] =
+ * ticks of the constant 100 MHz counter (s_memrealtime) spent in it: clock = ticks[0] / ticks[1] x 100 MHz.  `ticks`: four
+ * device uint64 (two results, two scratch words).  Not capture-safe. */
+int gs_clock_probe(uint64_t* ticks, int32_t iters, void* stream);
 
 /* process-wide tuning switches for experiments and A/B measurements.  Without effect on the results: "xcd_map" (1: the
  * four quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's

@@ -375,10 +375,10 @@ static inline uint8_t ov_act(const uint64_t* key, const uint8_t* act, int lo, in
 static void pixel_walk(const uint32_t* point_list, uint32_t r0, uint32_t r1, const float* xy, const float* conic_opacity,
                        const float* rgb, float pxf, float pyf, const uint64_t* okey, const uint8_t* oact, int lo, int hi,
                        float C[3], float* T_out, uint32_t* last_out, float* margin, OrCand* cands, int* ncand, int maxc,
-                       const float* eps) {
+                       const float* eps, uint32_t* blended_out) {
     float T = 1.0f;
     C[0] = C[1] = C[2] = 0.f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t contributor = 0, last = 0, blended = 0;
     float mg = INFINITY;
     for (uint32_t j = r0; j < r1; j++) {
         contributor++;
@@ -417,9 +417,11 @@ static void pixel_walk(const uint32_t* point_list, uint32_t r0, uint32_t r1, con
         for (int c = 0; c < 3; c++) C[c] += rgb[3 * g + c] * alpha * T;
         T = test_T;
         last = contributor;
+        blended++;
     }
     *T_out = T;
     *last_out = last;
+    if (blended_out) *blended_out = blended;
     if (margin) *margin = mg;
 }
 
@@ -427,7 +429,8 @@ static void pixel_walk(const uint32_t* point_list, uint32_t r0, uint32_t r1, con
 int or_render_forward_ex(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                          const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
                          int n_over, const uint64_t* over_key, const uint8_t* over_act,
-                         float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/, float* margin /*HW or NULL*/) {
+                         float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/, float* margin /*HW or NULL*/,
+                         uint32_t* n_blended /*HW or NULL: pairs actually composited per pixel*/) {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
@@ -443,7 +446,7 @@ int or_render_forward_ex(int W, int H, const uint32_t* ranges, const uint32_t* p
                 float T, C[3];
                 uint32_t last;
                 pixel_walk(point_list, r0, r1, xy, conic_opacity, rgb, (float)pxi, (float)pyi, over_key, over_act, lo, hi, C, &T,
-                           &last, margin ? margin + pid : NULL, NULL, NULL, 0, NULL);
+                           &last, margin ? margin + pid : NULL, NULL, NULL, 0, NULL, n_blended ? n_blended + pid : NULL);
                 final_T[pid] = T;
                 n_contrib[pid] = last;
                 for (int c = 0; c < 3; c++) out_color[(size_t)c * H * W + pid] = C[c] + T * bg[c];
@@ -455,7 +458,7 @@ int or_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* poin
                       const float* xy, const float* conic_opacity, const float* rgb, const float* bg,
                       float* out_color /*3HW*/, float* final_T /*HW*/, uint32_t* n_contrib /*HW*/) {
     return or_render_forward_ex(W, H, ranges, point_list, xy, conic_opacity, rgb, bg, 0, NULL, NULL, out_color, final_T,
-                                n_contrib, NULL);
+                                n_contrib, NULL, NULL);
 }
 
 /* Attribution.  For each of the `npix` listed pixels: what the device produced (dev_color[3 npix] channel-major,
@@ -475,7 +478,7 @@ static int explain_rec(const ExplainCtx* x, uint64_t* fkey, uint8_t* fact, float
     uint32_t last;
     /* (the forced table of this pixel, sorted by list index: insertion keeps it so) */
     pixel_walk(x->point_list, x->r0, x->r1, x->xy, x->co, x->rgb, x->pxf, x->pyf, fkey, fact, 0, nf, C, &T, &last, NULL,
-               depth_left > 0 ? cands : NULL, &nc, 24, x->eps);
+               depth_left > 0 ? cands : NULL, &nc, 24, x->eps, NULL);
     int ok = last == x->dev_last && fabsf(T - x->dev_T) <= x->tol_T * fmaxf(T, x->dev_T);
     for (int c = 0; ok && c < 3; c++) ok = fabsf(C[c] + T * x->bg[c] - x->dev_c[c]) <= x->tol_c;
     if (ok) return nf;

@@ -171,6 +171,7 @@ def render_forward(sc, st, bn, overrides=None, margin=False):
     final_T = np.zeros((H, W), np.float32)
     n_contrib = np.zeros((H, W), np.uint32)
     mg = np.zeros((H, W), np.float32) if margin else None
+    nb = np.zeros((H, W), np.uint32) if margin else None
     pl = np.ascontiguousarray(bn["point_list"]) if bn["D"] > 0 else np.zeros(1, np.uint32)
     if overrides is None and not margin:
         rc = lib().or_render_forward(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
@@ -180,11 +181,12 @@ def render_forward(sc, st, bn, overrides=None, margin=False):
         ov = overrides.cargs() if overrides is not None else _NO_OVERRIDES
         rc = lib().or_render_forward_ex(c_int(W), c_int(H), _ptr(bn["ranges"]), _ptr(pl), _ptr(st["xy"]),
                                         _ptr(st["conic_opacity"]), _ptr(st["rgb"]), _ptr(sc.bg), ov[0], ov[1], ov[2],
-                                        _ptr(out), _ptr(final_T), _ptr(n_contrib), _ptr(mg))
+                                        _ptr(out), _ptr(final_T), _ptr(n_contrib), _ptr(mg), _ptr(nb))
     assert rc == 0
     im = dict(color=out, final_T=final_T, n_contrib=n_contrib)
     if margin:
         im["margin"] = mg
+        im["n_blended"] = nb  # pairs composited per pixel (alpha >= 1/255, before the pixel was done)
     return im
 
 

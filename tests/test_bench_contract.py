@@ -4,6 +4,8 @@ import glob
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -127,3 +129,30 @@ def test_total_frames_is_config_4_as_stated_300_frames_partitioned_over_the_rank
     with pytest.raises(SystemExit):
         bench.main(["--gpus", "8", "--workload", "config4", "--total-frames", "300"])
     assert seen["cmd"][-6:] == ["--gpus", "8", "--workload", "config4", "--total-frames", "300"]
+
+
+def test_ranks_get_disjoint_core_slices():
+    """bench.pin_rank_to_cores: rank r of the node takes the r-th contiguous slice of the cores the process may run on
+    (set before anything touches the GPU).  Checked in child processes: the test process's own affinity stays as it is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps([bench.pin_rank_to_cores(int(sys.argv[1]), int(sys.argv[2])), sorted(os.sched_getaffinity(0))]))" % root)
+    ncores = len(os.sched_getaffinity(0))
+    if ncores < 4:
+        pytest.skip("fewer than four cores: pin_rank_to_cores leaves the scheduler alone")
+    seen = []
+    for rk in range(2):
+        r = subprocess.run([sys.executable, "-c", code, str(rk), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        label, cores = json.loads(r.stdout.strip().splitlines()[-1])
+        assert label is not None and label.endswith("(%d cores)" % (ncores // 2))
+        seen.append(set(cores))
+    assert not (seen[0] & seen[1]) and len(seen[0]) == len(seen[1]) == ncores // 2
+    # one rank per node, or switched off: nothing is pinned
+    r = subprocess.run([sys.executable, "-c", code, "0", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       cwd=root, env=dict(os.environ, GSPLAT_BENCH_NO_AFFINITY="1"))
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == [None, sorted(os.sched_getaffinity(0))]

@@ -260,6 +260,24 @@ def test_backward_matches_oracle(oracle, tile_rect, color_mode, cov_mode, deg):
         assert (gt.cpu().numpy()[culled] == 0).all(), name
 
 
+def test_pair_stats_counter_against_the_oracle(oracle):
+    """gs_pair_stats (bench.py's `pairs_valid`): the pairs actually composited, counted on the device from a finished
+    forward state, against the oracle's own count of blended pairs (n_blended; a handful of threshold decisions may fall
+    the other way: 1e-4 relative), and the walked pairs = the sum of the device's n_contrib, exactly."""
+    from gsplat_mi355 import debug
+    dev = torch.device("cuda:0")
+    n, W, H = 12000, 272, 200
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=1, seed=9, scale_mul=1.5)
+    bg = (0.0, 0.0, 0.0)
+    st = debug.forward_state(_settings(cam, cloud, bg, dev), cloud.xyz.to(dev), cloud.opacity.to(dev),
+                             shs=cloud.shs.to(dev), scales=cloud.scales.to(dev), rotations=cloud.rotations.to(dev))
+    fw = oracle.forward(helpers.oracle_scene(cloud, cam, bg=bg), margin=True)
+    want = int(fw["image"]["n_blended"].astype(np.int64).sum())
+    assert st["pairs_walked"] == int(st["image"]["n_contrib"].astype(np.int64).sum())
+    assert want > 100000 and abs(st["pairs_valid"] - want) <= 1e-4 * want
+    assert st["pairs_valid"] <= 64 * int(st["image"]["qcount"].astype(np.int64).sum())  # composited pairs are among the evaluated ones
+
+
 def test_empty_and_degenerate_inputs(oracle):
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device("cuda:0")
@@ -1325,6 +1343,68 @@ def test_fused_l1_loss_matches_oracle_and_torch(oracle, shape):
     assert np.array_equal(y.grad.cpu().numpy(), -want_grad)
     with pytest.raises(RuntimeError):
         l1_loss(a, b)  # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["small-image kernels", "large-image kernels", "precomputed inputs + opacity image",
+                                   "second call + mask loss"])
+def test_l1_fused_into_the_rasterizer_gives_the_bits_of_the_separate_l1_loss(oracle, scene):
+    """Row N2, "producing dL/dimage directly in the layout K7 reads": render(..., l1_target=gt) returns mean |image - gt|
+    (train.py:121 / utils/loss_utils.py:21-22) as a by-product of the render launch, and the backward forms that loss's
+    gradient per pixel in its own prologue -- no gradient image.  Against the separate path (l1_loss on the rendered image
+    -> a gradient image -> the rasterizer's backward): the loss value to summation order, EVERY gradient bit for bit -- also
+    with a non-unit weight on the loss, with another consumer of the image beside it, with the opacity image in the
+    same pass and with the reference's second call; the value also against the oracle's L1 of the same image."""
+    from gsplat_mi355.render import Pipe, l1_loss, render
+    dev = torch.device("cuda:0")
+    n, W, H = (9000, 208, 160) if scene != "large-image kernels" else (30000, 1040, 800)  # (800 x 1040: 3250 tiles > 2048)
+    cloud, cam = helpers.cloud_and_camera(n, W, H, sh_degree=2, seed=17, scale_mul=1.3 if n < 10000 else 2.0)
+    gen = torch.Generator().manual_seed(3)
+    gt = torch.rand(3, H, W, generator=gen).to(dev)
+    gimg = (torch.randn(3, H, W, generator=gen) * 1e-6).to(dev)  # a second consumer of the image, as SSIM would be
+    gmask = (torch.rand(1, H, W, generator=gen) > 0.5).float().to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    precomp = scene in ("precomputed inputs + opacity image", "second call + mask loss")
+    pipe = Pipe(compute_cov3D_python=precomp, fuse_opacity=(scene == "precomputed inputs + opacity image"))
+    want_opacity = scene in ("precomputed inputs + opacity image", "second call + mask loss")
+
+    def run(fused):
+        pc = _ConvertedCloud(cloud, cam, dev) if precomp else cloud.to(dev)
+        leaves = ([pc.xyz, pc.opacity, pc.cov6, pc.colors] if precomp else
+                  [pc.xyz, pc.opacity, pc.scales, pc.rotations, pc.shs])
+        for t in leaves:
+            t.requires_grad_(True)
+        pkg = render(cam.to(dev), pc, pipe, bg, colors_precomp=pc.colors if precomp else None, return_opacity=want_opacity,
+                     l1_target=gt if fused else None)
+        l1 = pkg.l1 if fused else l1_loss(pkg.render, gt)
+        loss = 0.8 * l1 + (pkg.render * gimg).sum()
+        if want_opacity:
+            loss = loss + 0.1 * l1_loss(pkg.opacity_render, gmask)
+        loss.backward()
+        torch.cuda.synchronize()
+        cam.to("cpu")
+        return (float(l1.detach()), pkg.render.detach().cpu().numpy(),
+                [t.grad.clone() for t in leaves] + [pkg.viewspace_points.grad.clone()])
+
+    v_sep, img_sep, g_sep = run(False)
+    v_fus, img_fus, g_fus = run(True)
+    assert np.array_equal(img_sep, img_fus)
+    assert v_fus == pytest.approx(v_sep, rel=2e-6) and v_fus > 0
+    assert v_fus == pytest.approx(oracle.l1_loss(img_fus, gt.cpu().numpy())[0], rel=2e-6)
+    for k, (a, b) in enumerate(zip(g_sep, g_fus)):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b), k
+    # the loss alone (no other consumer: the backward is given no gradient image at all), and its value under no_grad
+    pc = cloud.to(dev)
+    pc.xyz.requires_grad_(True)
+    pkg = render(cam.to(dev), pc, Pipe(), bg, l1_target=gt)
+    pkg.l1.backward()
+    pc2 = cloud.to(dev)
+    pc2.xyz.requires_grad_(True)
+    l1_loss(render(cam, pc2, Pipe(), bg).render, gt).backward()
+    assert torch.equal(pc.xyz.grad, pc2.xyz.grad)
+    with torch.no_grad():
+        assert float(render(cam, pc2, Pipe(), bg, l1_target=gt).l1) == float(pkg.l1.detach())
+    cam.to("cpu")
 
 
 @pytest.mark.gpu
