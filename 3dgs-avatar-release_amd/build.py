@@ -68,11 +68,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    # render_bwd.hip issues LDS reads in one inline-asm block and waits for them in the next: verify in the generated
-    # code that nothing in between touches the registers they land in (tools/check_inflight.py)
-    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    # render_bwd.hip's exec-masked LDS reads land in live registers while other instructions run: verify in the generated code
+    # that nothing between their issue and their wait touches those registers (check_inflight.py, next to this file)
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
     import check_inflight
-    check_inflight.check(os.path.join(OBJ_DIR, "render_bwd.o"))
+    check_inflight.check(os.path.join(OBJ_DIR, "render_bwd.o"), cc)
     # code-object extracts that `llvm-objdump --offloading` leaves next to what it inspects do not belong in a directory
     # that travels to the GPU box with every push
     for d in (OUT_DIR, OBJ_DIR):

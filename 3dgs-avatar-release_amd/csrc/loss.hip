@@ -93,9 +93,35 @@ int launch_bce_loss(const float* x, const float* y, int64_t n, float* loss, floa
     return GS_OK;
 }
 
+// The same sum for MANY partials (the fused L1: one per quadrant, 16 384 at 1024 x 1024): one workgroup of 1024 threads, every
+// thread's loads requested eight at a time before they are added (as a plain strided loop over 256 threads the launch took
+// 16 us at config 3: 64 dependent round trips per thread).  Fixed order: thread t adds its partials t, t + 1024, ... in
+// index order, the threads' sums go through the DPP ladder and the 16 wave sums are added in wave order.
+__global__ __launch_bounds__(1024) void loss_final_wide_kernel(const float* __restrict__ partial, int nparts, float inv_n,
+                                                               float* __restrict__ loss) {
+    __shared__ float ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float acc = 0.f;
+    for (int i0 = tid; i0 < nparts; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + u * 1024 < nparts) ? partial[i0 + u * 1024] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ws[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; w++) t += ws[w];
+        loss[0] = t * inv_n;
+    }
+}
+
 int launch_loss_final(const float* partial, int nparts, float inv_n, float* loss, hipStream_t s) {
     // (no stage scope of its own: the fused L1 calls it from inside the render_fwd stage, and stage scopes do not nest)
-    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, partial, nparts, inv_n, loss);
+    hipLaunchKernelGGL(loss_final_wide_kernel, dim3(1), dim3(1024), 0, s, partial, nparts, inv_n, loss);
     GS_LAUNCH_CHECK("loss_final", 0, s);
     return GS_OK;
 }

@@ -54,7 +54,10 @@ __device__ __forceinline__ float ring_ror1(float v) {
 // instruction costs the same with 1 or 64 lanes on): here the LDS unit does it instead.  The lanes of `m1 & ~mask` (those
 // that switch at the NEXT step; the accumulation is the last thing of a step that reads the entry... and it does not)
 // read their new entry from its staged copy straight into the working registers (q0, q1, q2): no other lane is written.
-// The reads are issued in front of the first nine instructions and waited for behind the second nine.
+// Round 4: the reads are issued AND waited for inside one asm statement -- in front of and behind the second set's nine
+// instructions and the two ring rotations that end a step -- so the compiler never sees a point where loads into q0 / q1
+// / q2 are in flight.  (Until round 3 they were issued in the first set's statement and waited for in the second's, with
+// a disassembly check at build time as the only guard; same-box A/B of the one-statement form: render_bwd 1 us faster.)
 typedef float bwd_f4 __attribute__((ext_vector_type(4)));
 template <bool SECOND>
 __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], unsigned long long mask, float Gd, float dx,
@@ -62,11 +65,9 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
                                                  float gz, unsigned long long m1, uint32_t lds_addr, bwd_f4& q0, bwd_f4& q1,
                                                  bwd_f4& q2, float& rot0, float& rot1) {
     unsigned long long save;
-#ifdef GS_SWITCH_ONE_BLOCK
-    // Issue and wait inside ONE asm statement (as switch_entry): the compiler never sees a point where loads into q0 / q1 /
-    // q2 are in flight.  The first statement is the X set alone; the second issues the reads, runs the Y set (and the
-    // caller's two ring rotations, `rot0` / `rot1`) in their shadow and waits.  The 30-operand limit of an asm statement
-    // is what keeps the X set out of it.
+    // The first statement is the X set alone; the second issues the reads, runs the Y set (and the caller's two ring
+    // rotations, `rot0` / `rot1`) in their shadow and waits.  The 30-operand limit of an asm statement is what keeps the X
+    // set out of it.  (SECOND: q2 = (b, r2, g2, b2), 16 bytes; otherwise only its first word is used: a 4-byte read.)
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[m]\n\t"
@@ -129,72 +130,6 @@ __device__ __forceinline__ void split_accumulate(float (&x)[9], float (&y)[9], u
 #undef GS_ACC_Y
 #undef GS_ACC_Y_OUT
 #undef GS_ACC_Y_IN
-#else
-    // (SECOND: q2 = (b, r2, g2, b2), 16 bytes; otherwise only its first word is used: a 4-byte read, half the LDS cycles)
-#define GS_ACC_X                                     \
-        "s_mov_b64 exec, %[m]\n\t"                   \
-        "v_fmac_f32 %[x0], %[Gd], %[dx]\n\t"         \
-        "v_fmac_f32 %[x1], %[Gd], %[dy]\n\t"         \
-        "v_fmac_f32 %[x2], %[tdx], %[dx]\n\t"        \
-        "v_fmac_f32 %[x3], %[tdx], %[dy]\n\t"        \
-        "v_fmac_f32 %[x4], %[tdy], %[dy]\n\t"        \
-        "v_add_f32 %[x5], %[x5], %[Gd]\n\t"          \
-        "v_fmac_f32 %[x6], %[w], %[gx]\n\t"          \
-        "v_fmac_f32 %[x7], %[w], %[gy]\n\t"          \
-        "v_fmac_f32 %[x8], %[w], %[gz]\n\t"          \
-        "s_mov_b64 exec, %[sv]"
-#define GS_ACC_X_OUT [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), \
-                     [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [q0] "+v"(q0), [q1] "+v"(q1)
-#define GS_ACC_IN [m] "s"(mask), [m1] "s"(m1), [a] "v"(lds_addr), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), \
-                  [tdy] "v"(tdy), [w] "v"(wgt), [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
-    if constexpr (SECOND) {
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_andn2_b64 exec, %[m1], %[m]\n\t"
-            "ds_read_b128 %[q0], %[a]\n\t"
-            "ds_read_b128 %[q1], %[a] offset:16\n\t"
-            "ds_read_b128 %[q2], %[a] offset:32\n\t" GS_ACC_X
-            : GS_ACC_X_OUT, [q2] "+v"(q2), [sv] "=&s"(save)
-            : GS_ACC_IN
-            : "memory", "scc");
-    } else {
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_andn2_b64 exec, %[m1], %[m]\n\t"
-            "ds_read_b128 %[q0], %[a]\n\t"
-            "ds_read_b128 %[q1], %[a] offset:16\n\t"
-            "ds_read_b32 %[q2], %[a] offset:32\n\t" GS_ACC_X
-            : GS_ACC_X_OUT, [q2] "+v"(q2.x), [sv] "=&s"(save)
-            : GS_ACC_IN
-            : "memory", "scc");
-    }
-#undef GS_ACC_X
-#undef GS_ACC_X_OUT
-#undef GS_ACC_IN
-    // (nothing may touch q0 / q1 / q2 between the two blocks: their loads are in flight.  The blocks are adjacent
-    // statements; the second one names the registers as in / out operands, so it cannot be moved in front of a use.)
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_andn2_b64 exec, %[sv], %[m]\n\t"
-        "v_fmac_f32 %[y0], %[Gd], %[dx]\n\t"
-        "v_fmac_f32 %[y1], %[Gd], %[dy]\n\t"
-        "v_fmac_f32 %[y2], %[tdx], %[dx]\n\t"
-        "v_fmac_f32 %[y3], %[tdx], %[dy]\n\t"
-        "v_fmac_f32 %[y4], %[tdy], %[dy]\n\t"
-        "v_add_f32 %[y5], %[y5], %[Gd]\n\t"
-        "v_fmac_f32 %[y6], %[w], %[gx]\n\t"
-        "v_fmac_f32 %[y7], %[w], %[gy]\n\t"
-        "v_fmac_f32 %[y8], %[w], %[gz]\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]),
-          [y6] "+v"(y[6]), [y7] "+v"(y[7]), [y8] "+v"(y[8]), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [sv] "=&s"(save)
-        : [m] "s"(mask), [Gd] "v"(Gd), [dx] "v"(dx), [dy] "v"(dy), [tdx] "v"(tdx), [tdy] "v"(tdy), [w] "v"(wgt),
-          [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz)
-        : "memory", "scc");
-    rot0 = ring_ror1(rot0);
-    rot1 = ring_ror1(rot1);
-#endif
 }
 
 // The per-entry values the inner loop reads, as the three 16-byte quads they are staged with in LDS:

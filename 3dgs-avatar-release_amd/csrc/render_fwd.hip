@@ -53,10 +53,6 @@ struct FwdArgs {
     const float* __restrict__ l1_target;
     float* __restrict__ l1_part;
 };
-// |c - target| over the three channels of pixel `pid` (c = the composited colour, background included)
-__device__ __forceinline__ float l1_pixel(const FwdArgs& A, const size_t pid, const size_t HW, const float c0, const float c1, const float c2) {
-    return (fabsf(c0 - A.l1_target[pid]) + fabsf(c1 - A.l1_target[HW + pid])) + fabsf(c2 - A.l1_target[2 * HW + pid]);
-}
 __device__ __forceinline__ void forward_side_fill(const FwdArgs& A) {
     if (!A.marks) {  // not this launch's job; a state word it owns must not keep what an earlier use of the memory left there
         if (A.marks_flag && blockIdx.x == 0 && threadIdx.x == 0) *A.marks_flag = 0u;
@@ -119,6 +115,13 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     // v_cndmask): no scalar mask arithmetic in the inner loop -- the CU's single scalar unit was the
     // bottleneck of the mask-based version.
     float T = inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    // the fused L1 loss's target values of this pixel: requested NOW (a load at the wave's end is a stall of a whole
+    // memory latency with nothing left to hide it behind: + 11 us on the launch at config 3 when it was there)
+    float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;
+    if (A.l1_target && inside) {
+        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+        gt0 = A.l1_target[pid]; gt1 = A.l1_target[HW + pid]; gt2 = A.l1_target[2 * HW + pid];
+    }
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;  // wave-uniform: compacted entries staged so far
     int nck = 0;                   // checkpoints written so far (chunks of the backward begun, less one)
@@ -276,7 +279,7 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
         out_color[pid] = o0;
         out_color[HW + pid] = o1;
         out_color[2 * HW + pid] = o2;
-        if (A.l1_target) l1 = l1_pixel(A, pid, HW, o0, o1, o2);
+        l1 = (fabsf(o0 - gt0) + fabsf(o1 - gt1)) + fabsf(o2 - gt2);
     }
     if (A.l1_target) {  // (wave-uniform) the quadrant's share of the fused L1 loss, summed in the DPP ladder's fixed order
         l1 = wave_sum(l1);
@@ -379,11 +382,26 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
     // bookkeeping hangs off the chain instead of sitting on it.  The same multiplications in the same order as before: T,
     // final_T, n_contrib, the recorded lists and the colours are bit for bit what the frozen-sign form produced.
     float Tc = inside ? 1.0f : 0.0f, Tf = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;  // C: this lane's share of the pixel's colour
+    float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // the fused L1 loss's target values of this pixel, requested up front (render_quadrant_1)
+    if (A.l1_target && inside && e0) {
+        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+        gt0 = A.l1_target[pid]; gt1 = A.l1_target[HW + pid]; gt2 = A.l1_target[2 * HW + pid];
+    }
     uint32_t last = 0, last_k = 0;
     uint32_t kcount = 0;
     int nck = 0;
     bool live = QX0 < W && QY0 < H;  // (workgroup-uniform) the quadrant has a pixel inside the image
 
+#ifdef FWD4_PROF
+    // variant build only (tools/fwd4_prof.py): cycles of thread 0 per phase, printed for the heaviest tile's quadrant 0
+    unsigned long long pf_t0 = __builtin_readcyclecounter(), pf_stage = 0, pf_loop = 0, pf_tail = 0, pf_mark = 0;
+    uint32_t pf_batches = 0, pf_steps = 0;
+#define PF_MARK() (pf_mark = __builtin_readcyclecounter())
+#define PF_ADD(x) do { const unsigned long long pf_n = __builtin_readcyclecounter(); x += pf_n - pf_mark; pf_mark = pf_n; } while (0)
+#else
+#define PF_MARK() ((void)0)
+#define PF_ADD(x) ((void)0)
+#endif
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     uint32_t pid_g = 0, pid_n = 0;  // (two deep, as in render_quadrant_1)
     if (live && tid < n) {
@@ -397,6 +415,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         // (the index fetched two batches ahead is waited for HERE, where everything older has long arrived: left pending,
         // the compiler waits for it -- vmcnt(0), i.e. for this batch's qlist store too -- right before the next prefetch)
         asm volatile("" : "+v"(pid_n));
+        PF_MARK();
         Staged s;
         bool hit;
         if (FQ) {
@@ -466,6 +485,11 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             ck_next = (k + BWD_CH < (uint32_t)chunks * BWD_CH) ? k + BWD_CH : 0xFFFFFFFFu;
             return true;
         };
+        PF_ADD(pf_stage);
+#ifdef FWD4_PROF
+        pf_batches++;
+        pf_steps += (lead + (uint32_t)cnt + 3u) / 4u;
+#endif
         const char* sp = reinterpret_cast<const char*>(srec) + e * 48;
         const uint32_t kstep0 = kbase - lead;              // compacted index of the batch's first step (its lead entries: done)
         const int nstaged = (int)lead + cnt;
@@ -529,6 +553,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
             if (ck_due(kstep0 + (uint32_t)j)) checkpoint(kstep0 + (uint32_t)j);
             step(a0, b0, c0);
         }
+        PF_ADD(pf_loop);
         {
             uint32_t lk = max(last_k, qperm<QP_X1>(last_k));
             lk = max(lk, qperm<QP_X2>(lk));
@@ -540,7 +565,13 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         if (lane == 0) s_flag[wv] = alive ? 1u : 0u;
         lds_barrier();
         live = (s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) != 0u;  // every pixel of the quadrant frozen: stop
+        PF_ADD(pf_tail);
     }
+#ifdef FWD4_PROF
+    if (tid == 0 && blockIdx.x < 8)
+        printf("fwd4prof block %d tile %d q %d: list %d batches %u steps %u | cycles total %llu stage %llu loop %llu tail %llu\n", (int)blockIdx.x, tile, q, n,
+               pf_batches, pf_steps, (unsigned long long)(__builtin_readcyclecounter() - pf_t0), pf_stage, pf_loop, pf_tail);
+#endif
     {
         const uint32_t wm = wave_max_u32(last_k);
         if (lane == 0) s_lastk[wv] = wm;
@@ -563,7 +594,7 @@ __device__ __forceinline__ void render_quadrant_4(const FwdArgs& A, const int ti
         out_color[pid] = o0;
         out_color[HW + pid] = o1;
         out_color[2 * HW + pid] = o2;
-        if (A.l1_target) l1 = l1_pixel(A, pid, HW, o0, o1, o2);
+        l1 = (fabsf(o0 - gt0) + fabsf(o1 - gt1)) + fabsf(o2 - gt2);
     }
     if (A.l1_target) {  // (workgroup-uniform) the four waves' shares, added in wave order
         l1 = wave_sum(l1);

@@ -6,7 +6,8 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSPLAT_LIB_PATH: another build of the same library (A/B runs of kernel variants: tools/build_variant.sh)
+# GSPLAT_LIB_PATH: another build of the same library (A/B runs of kernel variants: `GSPLAT_VARIANT=name python build.py`
+# leaves it under variants/name/; tools/variant_cmp.sh, tools/ab_bench.sh)
 LIB_PATH = os.environ.get("GSPLAT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libgsplat_mi355.so")
 
 

@@ -41,7 +41,7 @@ def test_size_functions_and_status_strings(lib):
     s = lib.nbytes(L.gs_backward_scratch_bytes, 5_000_000, 200000, 1024, 1024)
     assert s >= 5_000_000 * 4 * 32  # eight fp32 sums per (pair, quadrant) row (the ninth is the row's mark word: binning state)
     assert lib.nbytes(L.knn_workspace_bytes, 50000) > 50000 * 16
-    for code in (0, -1, -2, -3, -4, -5):
+    for code in (0, -1, -2, -3, -4, -5, -6):
         assert len(L.gs_status_string(code)) > 0
     out = ctypes.c_size_t(0)
     assert L.gs_binning_bytes(1 << 30, 64, 64, ctypes.byref(out)) == -3  # GS_E_TOO_LARGE
@@ -151,3 +151,28 @@ def test_inference_context_offers_what_the_forward_uses_of_an_autograd_context()
     n_inputs = len(inspect.signature(dgr._RasterizeGaussians.forward).parameters) - 1  # (ctx)
     assert len(ictx.needs_input_grad) == n_inputs
     assert not any(ictx.needs_input_grad)
+
+
+def test_the_entry_switch_of_render_bwd_keeps_its_loads_inside_one_statement():
+    """render_bwd.hip's exec-masked LDS reads land in live registers; since round 4 each group is issued and waited for
+    inside one asm statement.  The gate that checks the GENERATED code (3dgs-avatar-release_amd/check_inflight.py, run by
+    build.py on every compile) is run here on the object the build left in-tree, so that it does not depend on build.py
+    alone: it must find the read groups (both render_bwd modes, the round-start switch and the in-step one) and nothing
+    that touches their destination registers before the wait."""
+    import importlib.util
+    pkg = os.path.join(ROOT, "3dgs-avatar-release_amd")
+    obj = os.path.join(pkg, "build", "render_bwd.o")
+    if not os.path.exists(obj):
+        import __graft_entry__
+        __graft_entry__.build()
+    spec = importlib.util.spec_from_file_location("check_inflight", os.path.join(pkg, "check_inflight.py"))
+    ci = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ci)
+    assert ci.check(obj, "hipcc") >= 8
+    src = open(os.path.join(pkg, "csrc", "render_bwd.hip")).read()
+    # every ds_read of the file sits in an asm statement that also holds its s_waitcnt
+    for stmt in src.split("asm volatile(")[1:]:
+        body = stmt[:stmt.index(");")]
+        if "ds_read_b" in body:
+            assert "s_waitcnt lgkmcnt(0)" in body or "GS_ACC_Y" in body
+    assert "s_waitcnt lgkmcnt(0)" in src[src.index("#define GS_ACC_Y"):src.index("#define GS_ACC_Y_OUT")]
