@@ -322,7 +322,8 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     if (cap > 0) {  // the backward's row marks, set on the side by the render launch (BinLayout::marks) -- or declared unset
-        ql.marks = gs_tune_get(GS_TUNE_FWD_MARKS) ? (uint4*)(b + B.marks) : nullptr;
+        // (not for a frame no backward can follow -- GsFwdArgs.forward_only: a frame rendered under no_grad)
+        ql.marks = (gs_tune_get(GS_TUNE_FWD_MARKS) && !a->forward_only) ? (uint4*)(b + B.marks) : nullptr;
         ql.mark_quads = (size_t)cap;
         ql.marks_flag = (uint32_t*)(b + B.marks_flag);
     }
@@ -484,7 +485,7 @@ int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, floa
     return launch_opacity_image((const float*)((const char*)img + I.final_T), a->bg, a->W, a->H, opacity, (hipStream_t)stream);
 }
 
-static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, void* binning,
                          size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
                          const float* dL_dpix, const float* dL_dopacity_img, void* scratch, size_t scratch_bytes,
                          const GsGrads* gr, void* stream, const GsSecondImage* second = nullptr) {
@@ -508,7 +509,7 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
     if (a->P == 0) return GS_OK;
     hipStream_t s = (hipStream_t)stream;
     const char* g = (const char*)geom;
-    const char* b = (const char*)binning;
+    char* b = (char*)binning;
     const char* im = (const char*)img;
     if (D > 0) {
         QuadLists ql;
@@ -520,8 +521,8 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
         ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
         // the row marks: in the binning state, where the forward has set every word to ROW_UNWRITTEN beside its render
         // kernel; if a backward has run on this state since (marks_flag), the tile-order launch's other workgroups do it
-        uint32_t* q8 = (uint32_t*)(const_cast<char*>(b) + B.marks);
-        uint32_t* marks_flag = (uint32_t*)(const_cast<char*>(b) + B.marks_flag);
+        uint32_t* q8 = (uint32_t*)(b + B.marks);
+        uint32_t* marks_flag = (uint32_t*)(b + B.marks_flag);
         uint32_t* order_b = (uint32_t*)((char*)scratch + scratch_rows_bytes(D) + scratch_sums_bytes(a->P));
         const bool own_order = gs_tune_get(GS_TUNE_BWD_ORDER) != 0;
         { StageScope sc_("tile_order", s);
@@ -553,10 +554,10 @@ static int backward_impl(const GsFwdArgs* a, const int32_t* radii, const void* g
     return launch_gaussian_backward(*a, radii, (const float*)(g + L.rec), (const uint32_t*)(g + L.tiles),
                                     (const uint32_t*)(g + L.clamped), D > 0 ? (const uint32_t*)(b + B.marks) : nullptr,
                                     (const float*)scratch, (float*)((char*)scratch + scratch_rows_bytes(D)),
-                                    D > 0 ? (uint32_t*)(const_cast<char*>(b) + B.marks_flag) : nullptr, *gr, s);
+                                    D > 0 ? (uint32_t*)(b + B.marks_flag) : nullptr, *gr, s);
 }
 
-int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t D, const float* out_color,
                 const float* dL_dpix, void* scratch, size_t scratch_bytes, const GsGrads* gr, void* stream) {
     return backward_impl(a, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, D, out_color, dL_dpix, nullptr,
@@ -564,7 +565,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
 }
 
 int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
-                             const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                             void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
                              const float* out_color, const float* dL_dpix, const float* dL_dopacity_img, void* scratch,
                              size_t scratch_bytes, const GsGrads* gr, void* stream) {
     if (!dL_dopacity_img) return GS_E_BAD_ARG;
@@ -573,7 +574,7 @@ int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const voi
 }
 
 int gs_backward_with_second(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
-                            const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                            void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
                             const float* out_color, const float* dL_dpix, const GsSecondImage* second, void* scratch,
                             size_t scratch_bytes, const GsGrads* grads, void* stream) {
     if (!second || !second->colors || !second->out_color || !second->dL_dpix || !second->img) return GS_E_BAD_ARG;

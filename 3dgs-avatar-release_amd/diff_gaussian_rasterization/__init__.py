@@ -288,8 +288,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     if (_FUSE_SECOND and _SHARE and not with_opacity and torch.is_grad_enabled() and colors_precomp is not None
             and colors_precomp.numel() and not colors_precomp.requires_grad and (sh is None or sh.numel() == 0)):
         dep = _second_render_dependency(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
-    _tls.grad_mode = torch.is_grad_enabled()  # (inside Function.forward grad mode is always off)
-    if not _tls.grad_mode:
+    if not torch.is_grad_enabled():
         # no_grad (the reference's render loop, render.py:51-62): no autograd node would be built, and Function.apply
         # costs ~10 us of Python per call for building none -- a tenth of a forward-only frame at 50k Gaussians
         color, radii, opacity, l1 = _RasterizeGaussians.forward(_InferenceCtx(), means3D, means2D, sh, colors_precomp, opacities,
@@ -406,7 +405,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             # sharing needs an autograd node to own the state (see _GeomCache): without one every call renders in full
             # (needs_input_grad reflects the inputs' requires_grad flags also under no_grad -- render()'s means2D leaf
             # always has one -- where no node exists to own anything: inference frames skip the bookkeeping altogether)
-            share = _SHARE and getattr(_tls, "grad_mode", True) and any(ctx.needs_input_grad)
+            # (whether a node exists is read off the context's type -- an _InferenceCtx is what rasterize_gaussians passes
+            # under no_grad -- not off thread-local state a direct _RasterizeGaussians.apply call would find stale)
+            inference = isinstance(ctx, _InferenceCtx)
+            if inference:
+                a.forward_only = 1  # no backward can follow: the render launch need not prepare the backward's row marks
+            share = _SHARE and not inference and any(ctx.needs_input_grad)
             gkey = (_geom_cache.key(raster_settings, means3D, opacities, scales, rotations, cov3Ds_precomp, stream_h,
                                     capturing)
                     if share else None)

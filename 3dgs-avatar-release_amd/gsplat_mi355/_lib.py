@@ -20,6 +20,7 @@ class GsFwdArgs(ctypes.Structure):
         ("scale_modifier", c_float), ("tanfovx", c_float), ("tanfovy", c_float),
         ("prefiltered", c_int32), ("debug", c_int32), ("tile_rect", c_int32), ("long_lists", c_int32),
         ("frame_stats", c_void_p), ("l1_target", c_void_p), ("l1_loss", c_void_p), ("l1_grad", c_void_p),
+        ("forward_only", c_int32),
     ]
 
 

@@ -13,6 +13,8 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 
 from . import _lib
 
+_DEBUG = __import__("os").environ.get("GSPLAT_DEBUG", "0") == "1"
+
 
 class Pipe(object):
     """pipeline.* keys the renderer reads (configs/config.yaml:89-92)."""
@@ -50,17 +52,21 @@ class RenderPackage(object):
             raise AttributeError(item)
 
 
-_zeros = {}  # (device, shape, dtype) -> an all-zero tensor, never written
+_zeros = {}  # device -> (shape, dtype, an all-zero tensor nobody writes): ONE per device, replaced when the shape changes
 
 
 def _zero_leaf(like):
-    key = (like.device, tuple(like.shape), like.dtype)
-    z = _zeros.get(key)
-    if z is None:
-        if len(_zeros) > 64:
-            _zeros.clear()
-        z = _zeros[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
-    return z.detach().requires_grad_(True)
+    """A fresh leaf over a cached all-zero storage: it only exists to receive dL/dmeans2D in `.grad` (the rasterizer never
+    reads its values), so its VALUES are shared between frames and must be treated as read-only by callers -- the
+    reference's own tensor was a private `zeros + 0`.  One cached buffer per device (densification changes N every few
+    hundred steps: older shapes are dropped, not kept).  GSPLAT_DEBUG=1: every call checks that the storage is still zero."""
+    ent = _zeros.get(like.device)
+    if ent is None or ent[0] != tuple(like.shape) or ent[1] != like.dtype:
+        ent = _zeros[like.device] = (tuple(like.shape), like.dtype, torch.zeros(like.shape, dtype=like.dtype, device=like.device))
+    elif _DEBUG and bool(ent[2].any()):
+        raise RuntimeError("gsplat_mi355.render: the shared all-zero storage behind `viewspace_points` was written to "
+                           "(its values are read-only; the gradient arrives in `.grad`)")
+    return ent[2].detach().requires_grad_(True)
 
 
 def render(data, pc, pipe, bg_color, scaling_modifier=1.0, colors_precomp=None, return_opacity=False, l1_target=None):

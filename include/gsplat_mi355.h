@@ -105,6 +105,9 @@ typedef struct GsFwdArgs {
     const float* l1_target;
     float* l1_loss;
     const float* l1_grad;
+    int32_t forward_only; /* !=0: no backward will follow this forward (a frame rendered under no_grad): the render launch does
+                           * not prepare the backward's row marks on the side (55 MB of streaming stores at config 3).  A
+                           * backward that is run on the state anyway prepares them itself, as after a first backward */
 } GsFwdArgs;
 
 /* The eight gradient outputs of upstream `rasterize_gaussians_backward`, in the order the
@@ -181,9 +184,9 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
  * gs_forward_render).  `scratch` holds gs_backward_scratch_bytes(num_rendered, P, W, H) bytes.
  * The binning state also holds the mark word of every gradient row the backward writes (all "unwritten" on entry): the
  * forward's render launch sets them on the side and says so in a state word; a backward that finds them used by an
- * earlier backward of the same forward sets them itself.  A backward therefore WRITES that part of `binning`
- * (the pointer is const for the lists and ranges it reads); two backwards of one forward must not run concurrently. */
-int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, const void* binning,
+ * earlier backward of the same forward sets them itself.  A backward therefore WRITES that part of `binning` (which is
+ * why the pointer is not const; the lists and ranges it only reads); two backwards of one forward must not run concurrently. */
+int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes, void* binning,
                 size_t binning_bytes, const void* img, size_t img_bytes, int64_t num_rendered,
                 const float* out_color, const float* dL_dpix, void* scratch, size_t scratch_bytes,
                 const GsGrads* grads, void* stream);
@@ -197,7 +200,7 @@ int gs_backward(const GsFwdArgs* a, const int32_t* radii, const void* geom, size
  * one render and one backward instead of two of each. ---- */
 int gs_opacity_image(const GsFwdArgs* a, const void* img, size_t img_bytes, float* opacity, void* stream);
 int gs_backward_with_opacity(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
-                             const void* binning, size_t binning_bytes, const void* img, size_t img_bytes,
+                             void* binning, size_t binning_bytes, const void* img, size_t img_bytes,
                              int64_t num_rendered, const float* out_color, const float* dL_dpix,
                              const float* dL_dopacity_img, void* scratch, size_t scratch_bytes, const GsGrads* grads,
                              void* stream);
@@ -219,7 +222,7 @@ typedef struct GsSecondImage {
     int32_t long_lists;
 } GsSecondImage;
 int gs_backward_with_second(const GsFwdArgs* a, const int32_t* radii, const void* geom, size_t geom_bytes,
-                            const void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
+                            void* binning, size_t binning_bytes, const void* img, size_t img_bytes, int64_t D,
                             const float* out_color, const float* dL_dpix, const GsSecondImage* second, void* scratch,
                             size_t scratch_bytes, const GsGrads* grads, void* stream);
 
