@@ -137,8 +137,11 @@ __global__ __launch_bounds__(TC_THREADS) void tile_count_kernel(const uint4* __r
                                                                  uint32_t* __restrict__ seg_start, int P, int gx,
                                                                  int gy, int band_rows, int nbands, int nseg, int ntiles,
                                                                  uint32_t* __restrict__ seg_cnt,
-                                                                 uint32_t* __restrict__ tile_tot) {
+                                                                 uint32_t* __restrict__ tile_tot,
+                                                                 uint32_t* __restrict__ xcc_mask) {
     __shared__ int grid[TC_CELLS];
+    // (the chunk-parallel forward hands its work out per XCD: which XCDs this frame's launches run on)
+    if (xcc_mask && threadIdx.x == 0) atomicOr(xcc_mask, 1u << xcc_id());
     __shared__ unsigned long long sb_scratch[16];
     __shared__ uint32_t s_seg[TB_MAX_SEG + 2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -278,11 +281,14 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
     // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
     // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
     uint32_t wide_from = 0xFFFFFFFFu;
+    uint32_t ch = 0;  // (mark == 2) entries per chunk of the chunk-parallel forward; 0: no tile is cut this frame
+    uint32_t xmask = 0;
     if (mode == 2) {
         const unsigned long long D = *pc.dev;
-        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
-        if (ll.stats) {
-            // how many such tiles, and the longest list (GsFwdArgs.frame_stats: diagnostics)
+        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / (unsigned long long)ll.total_div, 0x7FFFFFFFull));
+        if (ll.mark == 2 && D <= FWDC_SPARSE_PAIRS) wide_from = FWD4_MIN_LIST;
+        if (ll.stats || ll.mark == 2) {
+            // how many such tiles, and the longest list (GsFwdArgs.frame_stats: diagnostics; the chunk size below)
             uint32_t nlong = 0;
             if (HELD) {
 #pragma unroll
@@ -297,27 +303,84 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
             __syncthreads();  // (wsum is free again: the scan above has read it)
             if (lane == 0) wsum[wid] = nlong;
             __syncthreads();
-            if (tid == 0) {
-                uint32_t tot = 0;
-                for (int w = 0; w < 16; w++) tot += wsum[w];
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; w++) tot += wsum[w];
+            if (tid == 0 && ll.stats) {
                 __hip_atomic_store(&ll.stats[0], (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&ll.stats[1], (long long)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            xmask = (ll.mark == 2 && ll.xcc_mask) ? (*ll.xcc_mask & 0xFFu) : 0u;
+            if (xmask && tot > 0 && tot <= FWDC_MAX_UNITS / 2 && D <= (unsigned long long)pc.cap) {
+                // The chunk size: sum over the marked tiles of ceil(n / ch) <= D / ch + (their number) -- the smallest
+                // power-of-two multiple of FWDC_CH_MIN for which that bound fits the unit table.  A function of the
+                // frame's counts alone (not of the order the threads arrive in): the cut, and with it the association of
+                // every sum, is the same on every run.
+                ch = ll.ch_min;
+                while (D / ch + tot > (unsigned long long)FWDC_MAX_UNITS && ch < 0x40000000u) ch <<= 1;
+            }
+            __syncthreads();  // (wmax has been read by every thread long ago; wsum by all of them just now)
+            if (tid == 0) wmax[0] = 0u;  // units handed out
+            if (tid < 16) wsum[tid] = 0u;   // [0..7] chunks given to every XCD, [8..15] items given to it
+            __syncthreads();
         }
         if (!ll.mark) wide_from = 0xFFFFFFFFu;
+        if (ll.mark == 2 && ch == 0) wide_from = 0xFFFFFFFFu;
     }
+    // (mark == 2) a marked tile of at least two chunks takes the next ceil(n / ch) units -- consecutive, chunk c at
+    // unit u0 + c: a chunk's wave only ever waits for waves of LOWER block indices (render_fwd.hip)
+    auto place = [&](const int t, const uint32_t wk) {
+        bool marked = wk > wide_from;
+        const uint32_t pos = atomicAdd(&hist[bin_of(wk)], 1u);  // the tile's place in the launch order (heaviest first)
+        if (marked && ch) {
+            const uint32_t nch = (wk + ch - 1u) / ch;
+            marked = nch >= 2u;
+            if (marked) {
+                const uint32_t u0 = atomicAdd(&wmax[0], nch);
+                // the tile's waves all run on ONE XCD (they hand values to each other through its L2).  Which one: the
+                // marked tiles are the first of the launch order, heaviest first, and are dealt out over the XCDs the
+                // frame's launches run on in a boustrophedon (0 1 .. 7 7 .. 1 0): every XCD gets one tile of every size
+                // class, so the chunks spread about evenly.  (A look at per-XCD load counters does not: the threads of
+                // this workgroup place their tiles in the same instant and all see the same minimum -- measured, every
+                // long tile of the avatar frame on one XCD; round-robin over the units: 384 to 872 items per XCD.)  Any
+                // choice gives the same image.  The tile's 4 nch items are appended to that XCD's list in chunk order: a
+                // wave only ever waits for items in front of its own in the list
+                const uint32_t nx = (uint32_t)__popc(xmask);
+                const uint32_t ph = pos % (2u * nx);
+                uint32_t pick = ph < nx ? ph : 2u * nx - 1u - ph, best = 0;
+                for (uint32_t x = 0; x < 8; x++) {
+                    if ((xmask >> x) & 1u) {
+                        if (pick == 0u) { best = x; break; }
+                        pick--;
+                    }
+                }
+                atomicAdd(&wsum[best], nch);
+                const uint32_t i0 = atomicAdd(&wsum[8 + best], 4u * nch);
+                uint32_t* __restrict__ items = ll.cw_items + (size_t)best * (FWDC_MAX_UNITS * 4) + i0;
+                for (uint32_t c = 0; c < nch; c++) {
+                    ll.cw_units[u0 + c] = make_uint2((uint32_t)t, c | (nch << 16));
+                    for (uint32_t q = 0; q < 4; q++) items[4 * c + q] = (u0 + c) * 4u + q;
+                }
+            }
+        }
+        order[pos] = (uint32_t)t | (marked ? 0x80000000u : 0u);
+    };
     if (HELD) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (i * 1024 >= ntiles) break;
             const int t = i * 1024 + tid;
-            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t | (held[i] > wide_from ? 0x80000000u : 0u);
+            if (t < ntiles) place(t, held[i]);
         }
     } else {
-        for (int t = tid; t < ntiles; t += 1024) {
-            const uint32_t wk = tile_work(ranges, keys, mode, t);
-            order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (wk > wide_from ? 0x80000000u : 0u);
+        for (int t = tid; t < ntiles; t += 1024) place(t, tile_work(ranges, keys, mode, t));
+    }
+    if (ll.cw_hdr) {  // (workgroup-uniform) the work list's header: units in use, entries per chunk
+        __syncthreads();
+        if (tid == 0) {
+            ll.cw_hdr[0] = (mode == 2 && ch) ? wmax[0] : 0u;
+            ll.cw_hdr[1] = ch;
         }
+        if (tid < 8) ll.cw_hdr[4 + tid] = (mode == 2 && ch) ? wsum[8 + tid] : 0u;
     }
 }
 
@@ -610,7 +673,7 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32
         const int nbands = (gy + band_rows - 1) / band_rows;
         StageScope sc_("tile_count", s);
         hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, s, ranklist, chunk_pairs, seg_start, P,
-                           gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt, tc.tile_tot);
+                           gx, gy, band_rows, nbands, nseg, ntiles, seg_cnt, tc.tile_tot, tc.xcc_mask);
         GS_LAUNCH_CHECK("tile_count", debug, s);
     }
     {

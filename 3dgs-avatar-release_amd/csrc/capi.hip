@@ -2,6 +2,7 @@
 // the stages; no device allocation, no implicit synchronisation (except in debug mode).
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 
 static thread_local int g_last_hip = 0;
@@ -21,6 +22,13 @@ static void tune_defaults() {
     g_tune[GS_TUNE_NT_STORES].store(1);
     g_tune[GS_TUNE_BWD_CHUNKS].store(1);
     g_tune[GS_TUNE_FWD4].store(1);
+    // (GSPLAT_FWD4=0|1|2: the forward of the tiles marked as long on small images -- one wave per quadrant, four waves x four
+    // entries per step, or a wave per chunk of the list (render_fwd.hip: render_chunk); the same as gs_tuning("fwd4", v), read once)
+    if (const char* e = getenv("GSPLAT_FWD4")) g_tune[GS_TUNE_FWD4].store(atoi(e));
+    g_tune[GS_TUNE_FWDC_CH].store((int)FWDC_CH_MIN);  // entries per chunk of the chunk-parallel forward (a power of two >= 64)
+    g_tune[GS_TUNE_FWDC_DIV].store((int)FWD4_TOTAL_DIV);  // ... of the tiles whose list is longer than (frame's pairs) / this (and than FWD4_MIN_LIST)
+    if (const char* e = getenv("GSPLAT_FWDC_DIV")) { const int v = atoi(e); if (v >= 1) g_tune[GS_TUNE_FWDC_DIV].store(v); }
+    if (const char* e = getenv("GSPLAT_FWDC_CH")) { const int v = atoi(e); if (v >= 64 && (v & (v - 1)) == 0) g_tune[GS_TUNE_FWDC_CH].store(v); }
     g_tune[GS_TUNE_SHARED_QLIST].store(1);
     g_tune[GS_TUNE_ONES_FAST].store(1);
     g_tune[GS_TUNE_SMALL_TILES].store(BWD_CHUNK_MAX_TILES);
@@ -157,7 +165,19 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __
     }
 }
 
+__global__ __launch_bounds__(64) void xcc_probe_kernel(uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
 extern "C" {
+
+int gs_xcc_probe(uint32_t* xcc, int32_t n_blocks, void* stream) {
+    if (!xcc || n_blocks <= 0) return GS_E_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, xcc);
+    GS_LAUNCH_CHECK("xcc_probe", 0, s);
+    return GS_OK;
+}
 
 int gs_clock_probe(uint64_t* ticks, int32_t iters, void* stream) {
     if (!ticks || iters <= 0) return GS_E_BAD_ARG;
@@ -293,16 +313,21 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     const uint32_t* point_list = nullptr;
     const unsigned long long* count_dev = (const unsigned long long*)(g + L.count);
     const PairCount pc{count_dev, (uint32_t)cap};
-    (void)ntiles;
+    const bool chunked = forward_chunked(ntiles, a->long_lists);  // the marked tiles chunk-parallel (render_fwd.hip: render_chunk)
     int rc;
     if (a->P > 0) {
         point_list = cap > 0 ? (const uint32_t*)(b + B.point_list) : nullptr;
         rc = launch_tile_lists((const uint4*)(g + L.ranklist), (const uint32_t*)(g + L.chunk_pairs), (uint32_t*)(g + L.seg_start),
                                a->P, I.gx, I.gy,
-                               TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), I.tile_zero_bytes},
+                               TileCounts{(uint32_t*)(im + I.seg_cnt), (uint32_t*)(im + I.tile_tot), I.tile_zero_bytes,
+                                          chunked ? (uint32_t*)(im + I.cw_q) + 8 * FWDC_MAX_UNITS * 4 : nullptr},
                                ranges, (uint32_t*)(im + I.order),
                                cap > 0 ? (uint32_t*)(b + B.point_list) : nullptr, pc,
-                               LongLists{forward_small_image(ntiles, a->long_lists) ? 1 : 0, (long long*)a->frame_stats},
+                               LongLists{chunked ? 2 : (forward_small_image(ntiles, a->long_lists) ? 1 : 0), (long long*)a->frame_stats,
+                                         chunked ? (uint32_t*)(im + I.cw_hdr) : nullptr, chunked ? (uint2*)(im + I.cw_units) : nullptr,
+                                         (uint32_t)gs_tune_get(GS_TUNE_FWDC_CH), chunked ? (uint32_t*)(im + I.cw_items) : nullptr,
+                                         chunked ? (const uint32_t*)(im + I.cw_q) + 8 * FWDC_MAX_UNITS * 4 : nullptr,
+                                         chunked ? (uint32_t)gs_tune_get(GS_TUNE_FWDC_DIV) : (uint32_t)FWD4_TOTAL_DIV},
                                totals_zeroed, a->debug, s);
         if (rc != GS_OK) return rc;
     } else {
@@ -310,7 +335,7 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
         if (rc != GS_OK) return rc;
         StageScope sc_("ranges_order", s);
         rc = launch_tile_order(ranges, nullptr, 0, ntiles, (uint32_t*)(im + I.order), pc, FillJob{nullptr, 0},
-                               LongLists{0, nullptr}, a->debug, s);
+                               LongLists{0, nullptr, chunked ? (uint32_t*)(im + I.cw_hdr) : nullptr, nullptr}, a->debug, s);
         if (rc != GS_OK) return rc;
     }
     QuadLists ql;
@@ -319,6 +344,16 @@ static int forward_phase2(const GsFwdArgs* a, void* geom, size_t geom_bytes, voi
     ql.qcount = (uint32_t*)(im + I.tile_nmax);
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
+    if (chunked) {
+        ql.chunked = 1;
+        ql.cw_hdr = (const uint32_t*)(im + I.cw_hdr);
+        ql.cw_units = (const uint2*)(im + I.cw_units);
+        ql.cw_items = (const uint32_t*)(im + I.cw_items);
+        ql.cw_q = (uint32_t*)(im + I.cw_q);
+        ql.cw_flag = (uint32_t*)(im + I.cw_flag);
+        ql.cw_done = (uint32_t*)(im + I.cw_done);
+        ql.cw_rec = (float*)(im + I.cw_rec);
+    }
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     if (cap > 0) {  // the backward's row marks, set on the side by the render launch (BinLayout::marks) -- or declared unset
@@ -420,6 +455,7 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     char* b = (char*)binning;
     char* im = (char*)img;
     const int ntiles = I.gx * I.gy;
+    const bool chunked = forward_chunked(ntiles, a->long_lists);
     unsigned long long* not_ones = nullptr;
     if (a->P > 0) {
         StageScope sc_("recolor", s);
@@ -439,7 +475,9 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
         rc = launch_recolor(*a, (const float*)(gs + L.rec), (const uint32_t*)(gs + L.tiles), (float*)(g + L.rec),
                             (uint32_t*)(g + L.tiles), (uint32_t*)(g + L.clamped), not_ones,
                             CopyJob{(const uint32_t*)(is + I.ranges), (uint32_t*)(im + I.ranges), ntiles * 2},
-                            CopyJob{(const uint32_t*)(is + I.order), (uint32_t*)(im + I.order), ntiles}, not_ones ? &so : nullptr, s);
+                            CopyJob{(const uint32_t*)(is + I.order), (uint32_t*)(im + I.order), ntiles},
+                            chunked ? ZeroJob{(uint32_t*)(im + I.cw_flag), (int)((I.cw_q + (size_t)8 * FWDC_MAX_UNITS * 4 * 4 + 64 - I.cw_flag) / 4)} : ZeroJob{nullptr, 0},
+                            not_ones ? &so : nullptr, s);
         if (rc != GS_OK) return rc;
     } else {
         // (no Gaussians: no recolouring launch to ride in) the new image state's own copy of the tile ranges and launch order
@@ -460,6 +498,23 @@ int gs_forward_shared(const GsFwdArgs* a, const void* geom_src, const void* img_
     }
     ql.chunks = gs_tune_get(GS_TUNE_BWD_CHUNKS) ? I.bwd_chunks : 1;
     ql.four_waves = forward_small_image(I.gx * I.gy, a->long_lists) ? 1 : 0;
+    if (chunked && a->P > 0) {
+        // the first render's work list (the copied launch order carries its marks); this state's own hand-off words
+        // (cleared by the recolouring launch) and records; walking the recorded lists also the first render's records
+        ql.chunked = 1;
+        ql.cw_hdr = (const uint32_t*)(is + I.cw_hdr);
+        ql.cw_units = (const uint2*)(is + I.cw_units);
+        ql.cw_items = (const uint32_t*)(is + I.cw_items);
+        ql.cw_q = (uint32_t*)(im + I.cw_q);
+        ql.cw_flag = (uint32_t*)(im + I.cw_flag);
+        ql.cw_done = (uint32_t*)(im + I.cw_done);
+        ql.cw_rec = (float*)(im + I.cw_rec);
+        if (ql.src_qcount) {
+            ql.src_cw_flag = (const uint32_t*)(is + I.cw_flag);
+            ql.src_cw_rec = (const float*)(is + I.cw_rec);
+            ql.src_final_T = (const float*)(is + I.final_T);
+        }
+    }
     ql.ckpt = ql.chunks > 1 ? (float4*)(im + I.ckpt) : nullptr;
     ql.ck_start = ql.chunks > 1 ? (uint32_t*)(im + I.ck_start) : nullptr;
     ql.all_ones = (uint32_t*)(im + I.all_ones);  // (set by the render launch: 1 iff it left the speculative image alone)
@@ -760,6 +815,7 @@ int gs_binning_field(void* binning, int64_t D, int32_t W, int32_t H, int32_t fie
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
     if (!img || !out) return GS_E_BAD_ARG;
     const ImgLayout I = img_layout(W, H);
+    if (field >= 6 && field <= 9 && !I.cw_rec) return GS_E_BAD_ARG;  // (the chunk-parallel forward's state: small images only)
     char* m = (char*)img;
     switch (field) {
         case 0: *out = m + I.ranges; break;
@@ -768,6 +824,10 @@ int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out) {
         case 3: *out = m + I.tile_nmax; break;
         case 4: *out = m + I.ncon_c; break;
         case 5: *out = m + I.order; break;
+        case 6: *out = m + I.cw_hdr; break;    // 16 words: units in use, entries per chunk, .., [4..11] items per XCD
+        case 7: *out = m + I.cw_units; break;  // FWDC_MAX_UNITS x {tile, chunk | chunks << 16}
+        case 8: *out = m + I.cw_flag; break;   // 4 FWDC_MAX_UNITS words: hits + 1 | dead << 31
+        case 9: *out = m + I.cw_rec; break;    // 4 FWDC_MAX_UNITS records of FWDC_SLOTS x 64 floats
         default: return GS_E_BAD_ARG;
     }
     return GS_OK;
@@ -830,6 +890,16 @@ int gs_tuning(const char* name, int value) {
     if (strcmp(name, "ones_fast") == 0) { g_tune[GS_TUNE_ONES_FAST].store(value); return GS_OK; }
     if (strcmp(name, "shared_qlist") == 0) { g_tune[GS_TUNE_SHARED_QLIST].store(value); return GS_OK; }
     if (strcmp(name, "fwd4") == 0) { g_tune[GS_TUNE_FWD4].store(value); return GS_OK; }
+    if (strcmp(name, "fwdc_div") == 0) {
+        if (value < 1) return GS_E_BAD_ARG;
+        g_tune[GS_TUNE_FWDC_DIV].store(value);
+        return GS_OK;
+    }
+    if (strcmp(name, "fwdc_ch") == 0) {
+        if (value < 64 || (value & (value - 1)) != 0) return GS_E_BAD_ARG;
+        g_tune[GS_TUNE_FWDC_CH].store(value);
+        return GS_OK;
+    }
     if (strcmp(name, "bwd_chunks") == 0) { g_tune[GS_TUNE_BWD_CHUNKS].store(value); return GS_OK; }  // flip between frames only
     if (strcmp(name, "nt_stores") == 0) { g_tune[GS_TUNE_NT_STORES].store(value); return GS_OK; }
     if (strcmp(name, "fwd_marks") == 0) { g_tune[GS_TUNE_FWD_MARKS].store(value); return GS_OK; }  // 0: the backward sets its row marks itself (A/B)

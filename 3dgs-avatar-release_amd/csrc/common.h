@@ -130,7 +130,7 @@ static inline int bin_segments(const BinGrid& G, int P) {
 }
 
 // process-wide tuning switches (gs_tuning)
-enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_BWD_ORDER = 8, GS_TUNE_FWD_MARKS = 9, GS_TUNE_COUNT = 10 };
+enum { GS_TUNE_XCD_MAP = 0, GS_TUNE_DEPTH_SORT = 1, GS_TUNE_NT_STORES = 2, GS_TUNE_BWD_CHUNKS = 3, GS_TUNE_FWD4 = 4, GS_TUNE_SMALL_TILES = 5, GS_TUNE_SHARED_QLIST = 6, GS_TUNE_ONES_FAST = 7, GS_TUNE_BWD_ORDER = 8, GS_TUNE_FWD_MARKS = 9, GS_TUNE_FWDC_CH = 10, GS_TUNE_FWDC_DIV = 11, GS_TUNE_COUNT = 12 };
 int gs_tune_get(int key);
 
 // Backward in chunks (small images): a frame of few, long lists -- a trained avatar at 512 x 512 has ~150 tiles of 2000-7000
@@ -148,8 +148,27 @@ int gs_tune_get(int key);
 #define FWD4_TOTAL_DIV 320ull  // (160: avatar frame - 1.5 %; 640: configs 2 and 4 - 13 % / - 5 %; 1280: - 18 % / - 9 %)
 #endif
 
+// Chunk-parallel forward of the long lists (round 4, render_fwd.hip: render_chunk).  The tile_order job cuts the list of
+// every marked tile into CHUNKS of `ch` entries (FWDC_CH_MIN, doubled until the frame's chunks fit FWDC_MAX_UNITS) and
+// numbers the (tile, chunk) UNITS; the render launch runs one wave per (unit, quadrant) in front of its tile waves.
+#define FWDC_CH_MIN 256u
+// A frame of at most this many pairs leaves most of the chip idle whatever is done (a trained avatar at 512 x 512: 0.35 M):
+// every tile of more than two chunks is cut.  Above it only the tiles FWD4_TOTAL_DIV marks -- where the chip is busy
+// anyway the two passes of a cut tile are work added, not latency removed (configs 2 and 4 with every tile cut: render
+// launch 62 -> 112 us, 87 -> 190 us)
+#define FWDC_SPARSE_PAIRS 524288ull
+#define FWDC_MAX_UNITS 4096
+#define FWDC_MAX_TILES (FWDC_MAX_UNITS / 2)  // marked tiles per frame (each has at least two chunks)
+#ifdef FWDC_PROF
+#define FWDC_SLOTS 9            // (+ a slot of time stamps: tools/fwdc_prof.py)
+#else
+#define FWDC_SLOTS 8
+#endif
+                                // per (unit, quadrant): 8 x 64 floats -- P, T at the chunk's start, colour share (3), T after the last blend, last contributor (compacted + 1, position in the tile's list)
+#define FWDC_DEAD 0x80000000u   // in a flag word: every pixel of the quadrant was done before the chunk
+#define FWDC_SPIN_MAX (1 << 16) // polls of a predecessor's flag before the wave gives up (it never should: see render_chunk)
 struct ImgLayout {
-    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, all_ones, tile_zero_bytes, l1_part, ckpt, ck_start, total;
+    size_t ranges, n_contrib, final_T, ncon_c, tile_nmax, order, seg_cnt, tile_tot, all_ones, cw_flag, cw_done, cw_q, tile_zero_bytes, l1_part, ckpt, ck_start, cw_hdr, cw_units, cw_items, cw_rec, total;
     int gx, gy, bwd_chunks;
 };
 // `long_lists`: GsFwdArgs.long_lists (the few-long-lists machinery on an image of any size)
@@ -176,11 +195,31 @@ static inline ImgLayout img_layout(int W, int H, int long_lists = 0) {
     // recolor_kernel): the one-pass backward of both images then needs no colours of the second image at all
     L.all_ones = take(4);
     L.tile_zero_bytes = L.all_ones + 4 - L.tile_tot;
+    const bool fl = few_long_lists_mode((int)nt, long_lists);
+    const bool cw = fl && gs_tune_get(GS_TUNE_FWD4) == 2;  // (the chunk-parallel forward's state: only where it is switched on)
+    L.cw_flag = L.cw_done = L.cw_q = 0;
+    if (cw) {
+        // the chunk-parallel forward's hand-off words, cleared with the totals: per (unit, quadrant) "hits + 1" once the
+        // chunk's transmittance product is published; per quadrant the number of its chunks that are finished
+        L.cw_flag = take((size_t)FWDC_MAX_UNITS * 4 * 4);
+        L.cw_done = take(nt * 16);
+        // [XCD][item of its list]: 1 once a wave has taken the item; behind them one word: the XCDs this frame's launches
+        // run on (a bit each)
+        L.cw_q = take((size_t)8 * FWDC_MAX_UNITS * 4 * 4 + 64);
+        L.tile_zero_bytes = L.cw_q + (size_t)8 * FWDC_MAX_UNITS * 4 * 4 + 64 - L.tile_tot;
+    }
     L.l1_part = take(nt * 16);  // per quadrant: sum |out_color - l1_target| over its pixels (GsFwdArgs.l1_target)
-    L.bwd_chunks = few_long_lists_mode((int)nt, long_lists) ? BWD_KMAX : 1;
+    L.bwd_chunks = fl ? BWD_KMAX : 1;
     // [quadrant][chunk 1 .. bwd_chunks - 1][64 pixels] (T, C0, C1, C2) before the chunk's first entry
     L.ckpt = take(nt * 4 * (size_t)(L.bwd_chunks - 1) * 64 * 16);
     L.ck_start = take(nt * 4 * (size_t)L.bwd_chunks * 4);  // [quadrant][chunk]: first compacted entry of the chunk, ~0 = none
+    L.cw_hdr = L.cw_units = L.cw_items = L.cw_rec = 0;
+    if (cw) {
+        L.cw_hdr = take(64);                                   // [0] units in use, [1] entries per chunk, [4..11] items given to every XCD
+        L.cw_units = take((size_t)FWDC_MAX_UNITS * 8);         // {tile, chunk | chunks of the tile << 16}
+        L.cw_items = take((size_t)8 * FWDC_MAX_UNITS * 4 * 4); // [XCD][item]: unit * 4 + quadrant, a tile's items in chunk order
+        L.cw_rec = take((size_t)FWDC_MAX_UNITS * 4 * FWDC_SLOTS * 64 * 4);
+    }
     L.total = o;
     return L;
 }
@@ -335,6 +374,12 @@ __device__ __forceinline__ void segment_starts(const uint32_t* __restrict__ chun
     }
 }
 
+// the XCD (accelerator complex die: its own L2) this wave runs on
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7u;
+}
 __device__ __forceinline__ void zero_job(const ZeroJob z) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < z.words; k += gridDim.x * blockDim.x) z.ptr[k] = 0u;
 }
@@ -366,7 +411,8 @@ __device__ __forceinline__ void render_block_map(int b, int xmap, int* slot, int
     }
 }
 // the forward runs four waves per quadrant, and tile_order_kernel marks the tiles that use them all (render_fwd.hip)
-static inline bool forward_small_image(int ntiles, int long_lists) { return few_long_lists_mode(ntiles, long_lists) && gs_tune_get(GS_TUNE_FWD4) != 0; }
+static inline bool forward_small_image(int ntiles, int long_lists) { return few_long_lists_mode(ntiles, long_lists) && gs_tune_get(GS_TUNE_FWD4) == 1; }
+static inline bool forward_chunked(int ntiles, int long_lists) { return few_long_lists_mode(ntiles, long_lists) && gs_tune_get(GS_TUNE_FWD4) == 2; }
 static inline int render_grid_blocks(int ntiles, int xmap) { return xmap ? ((ntiles + 7) / 8) * 32 : ntiles * 4; }
 
 struct StageScope {
@@ -437,7 +483,7 @@ __device__ __forceinline__ void second_ones_body(const SecondOnes& A, const int 
 // `ones`: not null = the launch's other workgroups write the speculative all-ones image
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, CopyJob c0, CopyJob c1,
-                   const SecondOnes* ones, hipStream_t s);
+                   ZeroJob z0, const SecondOnes* ones, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits); ping-pongs between
@@ -465,10 +511,14 @@ int launch_rank_list(const uint32_t* sorted_idx, const float* rec, const uint32_
                      uint32_t* chunk_pairs, int P, int debug, hipStream_t s);
 // per-(segment, tile) pair counts; per-tile totals (integer atomics of the counting pass into words cleared beforehand:
 // `zero_bytes` from tile_tot on)
-struct TileCounts { uint32_t *seg_cnt, *tile_tot; size_t zero_bytes; };
+// (`xcc_mask`, may be null: every workgroup of the counting pass sets the bit of the XCD it runs on)
+struct TileCounts { uint32_t *seg_cnt, *tile_tot; size_t zero_bytes; uint32_t* xcc_mask = nullptr; };
 // what the tile-order launch of the forward also does: mark the tiles whose list is long against the frame's total in
 // the launch order (bit 31; render_fwd.hip) and report how many there are and the longest list (GsFwdArgs.frame_stats)
-struct LongLists { int mark; long long* stats; };
+// `mark`: 0 none, 1 the tiles the four-wave forward takes, 2 the tiles the chunk-parallel forward takes (+ its work list)
+struct LongLists { int mark; long long* stats; uint32_t* cw_hdr = nullptr; uint2* cw_units = nullptr; uint32_t ch_min = FWDC_CH_MIN;
+                   uint32_t* cw_items = nullptr; const uint32_t* xcc_mask = nullptr;
+                   uint32_t total_div = (uint32_t)FWD4_TOTAL_DIV; };
 int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32_t* seg_start, int P, int gx, int gy, TileCounts tc, uint32_t* ranges,
                       uint32_t* order, uint32_t* point_list, PairCount pc, LongLists ll, bool totals_zeroed, int debug,
                       hipStream_t s);
@@ -528,6 +578,19 @@ struct QuadLists {
     uint32_t* ncon_c;   // [H W]
     uint32_t* qcount;   // [tiles][4]
     int four_waves = 0;      // forward: four waves per quadrant, all used on the tiles marked in the launch order
+    // forward: the marked tiles chunk-parallel (render_chunk) -- the work list (this state's, or the first render's), this
+    // state's hand-off words and records, and for a second render the first one's
+    int chunked = 0;
+    const uint32_t* cw_hdr = nullptr;
+    const uint2* cw_units = nullptr;
+    const uint32_t* cw_items = nullptr;
+    uint32_t* cw_q = nullptr;
+    uint32_t* cw_flag = nullptr;
+    uint32_t* cw_done = nullptr;
+    float* cw_rec = nullptr;
+    const uint32_t* src_cw_flag = nullptr;
+    const float* src_cw_rec = nullptr;
+    const float* src_final_T = nullptr;
     // forward of a second render of the same geometry: the first render's per-quadrant counts and n_contrib (or null)
     const uint32_t* src_qcount = nullptr;
     const uint32_t* src_n_contrib = nullptr;

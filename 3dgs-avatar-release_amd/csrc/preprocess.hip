@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
                                                       float4* __restrict__ rec_dst, uint32_t* __restrict__ tiles_dst,
                                                       uint32_t* __restrict__ clamped_dst,
                                                       unsigned long long* __restrict__ not_ones, const CopyJob c0,
-                                                      const CopyJob c1, const int recolor_blocks, const SecondOnes ones,
+                                                      const CopyJob c1, const ZeroJob z0, const int recolor_blocks, const SecondOnes ones,
                                                       const int pixel_blocks) {
     if ((int)blockIdx.x >= recolor_blocks) {  // (workgroup-uniform) the side job: the all-ones image, speculatively
         second_ones_body(ones, (int)blockIdx.x - recolor_blocks, pixel_blocks);
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
     // the new image state's own copy of the tile ranges and the launch order (its backward reads them): two copy launches less
     for (int k = i; k < c0.words; k += recolor_blocks * (int)blockDim.x) c0.dst[k] = c0.src[k];
     for (int k = i; k < c1.words; k += recolor_blocks * (int)blockDim.x) c1.dst[k] = c1.src[k];
+    for (int k = i; k < z0.words; k += recolor_blocks * (int)blockDim.x) z0.ptr[k] = 0u;  // (the chunk-parallel forward's hand-off words)
     if (i >= P) return;
     float4 r0 = rec_src[(size_t)i * 3], r1 = rec_src[(size_t)i * 3 + 1], r2 = rec_src[(size_t)i * 3 + 2];
     const uint32_t tt = tiles_src[i];
@@ -253,14 +254,14 @@ __global__ __launch_bounds__(256) void recolor_kernel(int P, int deg, int M, con
 
 int launch_recolor(const GsFwdArgs& a, const float* rec_src, const uint32_t* tiles_src, float* rec_dst,
                    uint32_t* tiles_dst, uint32_t* clamped_dst, unsigned long long* not_ones, CopyJob c0, CopyJob c1,
-                   const SecondOnes* ones, hipStream_t s) {
+                   ZeroJob z0, const SecondOnes* ones, hipStream_t s) {
     const int recolor_blocks = (a.P + 255) / 256;
     const int pixel_blocks = ones ? (int)(((size_t)ones->W * ones->H + 255) / 256) : 0;
     const int side = ones ? pixel_blocks + ones->ntiles : 0;
     const SecondOnes none{};
     hipLaunchKernelGGL(recolor_kernel, dim3((unsigned)(recolor_blocks + side)), dim3(256), 0, s, a.P, a.sh_degree, a.M, a.means3D,
                        a.shs, a.colors_precomp, a.campos, reinterpret_cast<const float4*>(rec_src), tiles_src,
-                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst, not_ones, c0, c1, recolor_blocks,
+                       reinterpret_cast<float4*>(rec_dst), tiles_dst, clamped_dst, not_ones, c0, c1, z0, recolor_blocks,
                        ones ? *ones : none, pixel_blocks);
     GS_LAUNCH_CHECK("recolor", a.debug, s);
     return GS_OK;

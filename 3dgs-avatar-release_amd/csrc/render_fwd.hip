@@ -16,6 +16,7 @@
 // count up to the last contributor.  The backward therefore never re-derives relevance.
 #include "common.h"
 #include "blend.h"
+#include <type_traits>
 
 struct FwdArgs {
     const float4* __restrict__ rec;
@@ -52,6 +53,19 @@ struct FwdArgs {
     // quadrant, written by the quadrant's wave(s) from the colours they hold at the end of their walk
     const float* __restrict__ l1_target;
     float* __restrict__ l1_part;
+    // the chunk-parallel forward of the marked tiles (render_chunk; cw_blocks = 0: off): the first cw_blocks workgroups
+    // of the launch are its (unit, quadrant) waves
+    int cw_blocks;
+    const uint32_t* __restrict__ cw_hdr;
+    const uint2* __restrict__ cw_units;
+    const uint32_t* __restrict__ cw_items;
+    uint32_t* __restrict__ cw_q;
+    uint32_t* __restrict__ cw_flag;
+    uint32_t* __restrict__ cw_done;
+    float* __restrict__ cw_rec;
+    const uint32_t* __restrict__ src_cw_flag;  // (a second render of the same geometry) the first render's
+    const float* __restrict__ src_cw_rec;
+    const float* __restrict__ src_final_T;
 };
 __device__ __forceinline__ void forward_side_fill(const FwdArgs& A) {
     if (!A.marks) {  // not this launch's job; a state word it owns must not keep what an earlier use of the memory left there
@@ -287,17 +301,465 @@ __device__ __forceinline__ void render_quadrant_1(const FwdArgs& A, const int ti
     }
 }
 
+// Values handed from one wave to another INSIDE a launch (render_chunk).  All waves of a tile run on ONE XCD (the work is
+// handed out per XCD, see below), so the hand-off goes through that XCD's L2 and needs no cache maintenance at all:
+// stores and loads that pass the CU's own L1 (agent-scope relaxed atomics, `sc1`: a workgroup-scope load may be served by
+// the L1, where a polled flag stays what it was), a flag store behind `s_waitcnt vmcnt(0)` (a store is acknowledged by
+// the L2), read-modify-write atomics (they execute in the L2).  Across XCDs the same hand-off needs agent-scope release /
+// acquire FENCES, i.e. a write-back / invalidation of a whole L2 per fence: measured on the avatar frame, 0.51 ms for the
+// render launch with both fences, 0.32 ms with the release alone -- and without them a flag overtakes its data.
+__device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xstore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t xload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xrelease() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // this wave's stores have reached the L2
+__device__ __forceinline__ void xacquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the long lists CHUNK-PARALLEL.  A quadrant wave alone on its SIMD walks a list of 6000 entries in 0.13 ms
+// while most of the chip idles (a trained avatar at 512 x 512: 150 tiles, 600 quadrants, 2400 waves of the four-wave
+// kernel on 1024 SIMDs).  Compositing is associative over list segments, so the tile_order job cuts the list of every
+// marked tile into chunks of `ch` entries and this launch runs ONE WAVE PER (CHUNK, QUADRANT) in front of its tile
+// waves -- the one-wave loop at full occupancy instead of a dependent chain:
+//   pass A    P_c = the product of (1 - alpha) over the chunk's hits, per pixel, from 1, in list order; published with the
+//             number of hits (flag word = hits + 1);
+//   look-back the wave waits for the flags of the chunks in front of it (the same quadrant), adds up their hits (its
+//             first compacted index k0) and multiplies up T_s = ((1 P_0) P_1) ... P_{c-1};
+//   pass B    the chunk again, composited with T_i = T_s p_i, p_i = the running product of pass A (the same
+//             multiplications: the same bits) -- so the T the chunk ends with IS the next chunk's T_s, bit for bit, and
+//             "done" needs no flag: an entry is blended iff T_s p_{i+1} >= 1e-4, a condition that can only switch off
+//             once along the whole list; the compaction is recorded at k0 (qlist: one contiguous list per quadrant, as
+//             the one-wave kernel leaves it);
+//   finish    the wave that takes the quadrant's LAST ticket adds up the chunks' colour shares in chunk order, picks
+//             final_T (T after the last blended entry of the chunk where the pixel stopped, or the whole product) and
+//             the last contributor, writes the pixels, the quadrant's records and the backward's checkpoints (at chunk
+//             starts, at least BWD_CH and a sixteenth of the walk apart).
+// Against the one-wave walk the transmittance associates differently (T_s p_i instead of a single running product: a
+// few ulps), and so do the colour sums (per chunk, then over chunks); both are functions of the list and the chunk size
+// alone -- never of timing -- so a frame is bitwise repeatable, and a second render of the same geometry (FQ) takes T_s
+// and k0 from the first one's records and produces the bits of a stand-alone render.
+// Work hand-out: the tile_order job gives every marked tile to one XCD (round-robin over those the frame's launches run
+// on -- the counting pass notes them) and appends the tile's (chunk, quadrant) items to that XCD's list in chunk order.
+// The first cw_blocks workgroups of this launch are workers; worker r of XCD x takes item r of its list (see the
+// kernel).  So the waves of a tile share an L2; and a wave only ever waits for items IN FRONT of its own in the same
+// list -- taken by workers of lower index, which the dispatcher started earlier: they are running or done, and pass A
+// waits for nothing -- so the lowest unfinished item can always run.  The
+// poll loop is bounded all the same (FWDC_SPIN_MAX): a wave that gives up leaves a wrong quadrant behind, not a hung GPU.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef RENDER_CHUNK_INLINE
+#define RENDER_CHUNK_INLINE __forceinline__
+#endif
+#ifndef FWDC_WAVES_PER_SIMD
+#define FWDC_WAVES_PER_SIMD 6
+#endif
+#ifndef FIN_G
+#define FIN_G 2  // records of the finishing wave in flight together
+#endif
 template <bool FQ>
-__global__ __launch_bounds__(64) void render_fwd_kernel(const FwdArgs A) {
-    __shared__ float4 srec[66 * 3];
+__device__ RENDER_CHUNK_INLINE void render_chunk(const FwdArgs& A, const uint32_t item, float4* __restrict__ srec) {
+    const int u = (int)(item >> 2), q = (int)(item & 3u);
+    const uint32_t ch = A.cw_hdr[1];
+    const uint2 unit = A.cw_units[u];
+    const int tile = (int)unit.x;
+    const int c = (int)(unit.y & 0xFFFFu), nch = (int)(unit.y >> 16);
+    const float4* __restrict__ rec = A.rec;
+    const int W = A.W, H = A.H, gx = A.gx, chunks = A.chunks;
+    uint32_t* __restrict__ qlist = A.qlist;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x & 63;
+    const int QX0 = tx * TILE + 8 * (q & 1), QY0 = ty * TILE + 8 * (q >> 1);
+    const int px = QX0 + (lane & 7), py = QY0 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const bool inside = px < W && py < H;
+    const uint2 range = A.ranges[tile];
+    const int n_tile = (int)(range.y - range.x);
+    const uint32_t qbase = 4u * range.x + (uint32_t)q * (uint32_t)n_tile;
+    const size_t quad = (size_t)(tile * 4 + q);
+    const size_t r_me = (size_t)u * 4 + q;               // this wave's flag word / record
+    const size_t r_first = (size_t)(u - c) * 4 + q;      // ... chunk 0's of the same quadrant; chunk k: r_first + 4 k
+    float* __restrict__ rec_me = A.cw_rec + r_me * (FWDC_SLOTS * 64);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+
+    // One walk over entries [e0, e1) of `list`.  PASSB = false: p = the product of (1 - alpha) over the hits, `hits` = their
+    // number.  PASSB = true: the same product again, and with Ts the compositing: C0..2, Tl = T after the last blended entry
+    // (Ts if none), last_k / last = the last blended entry (compacted index + 1 from k0, position in the list), qlist.
+    float p = 1.0f, Ts = 0.0f, Tl = 0.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t hits = 0, last_k = 0, last = 0, k0 = 0;
+    auto walk = [&](auto passb_tag, const uint32_t* __restrict__ list, const int e0, const int e1) {
+        constexpr bool PASSB = decltype(passb_tag)::value;
+        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+        uint32_t pid_g = 0, pid_n = 0;
+        uint32_t kcount = 0;
+        float Tc = Ts;  // (pass B) T in front of the current entry = Ts p
+        p = 1.0f;
+        if (e0 + lane < e1) {
+            pid_g = list[e0 + lane];
+            p0 = rec[(size_t)pid_g * 3];
+            p1 = rec[(size_t)pid_g * 3 + 1];
+            if (PASSB) p2 = rec[(size_t)pid_g * 3 + 2];
+        }
+        if (e0 + 64 + lane < e1) pid_n = list[e0 + 64 + lane];
+        for (int base = e0; base < e1; base += 64) {
+            asm volatile("" : "+v"(pid_n));
+            Staged s;
+            bool hit;
+            if (FQ) {
+                stage_entry_convert(p0, p1, p2, s);
+                hit = base + lane < e1;
+            } else {
+                hit = stage_entry_quad(p0, p1, p2, QX0, QY0, s) && (base + lane < e1);
+            }
+            const unsigned long long bal = __ballot(hit);
+            const int cnt = __popcll(bal);
+            wave_lds_sync();
+            if (hit) {
+                const int slot = __popcll(bal & lt_mask);
+                s.c.w = __uint_as_float((uint32_t)(base + lane + 1));  // position in the tile's list (1-based)
+                srec[slot * 3] = s.a;
+                srec[slot * 3 + 1] = s.b;
+                if (PASSB) srec[slot * 3 + 2] = s.c;
+                if (PASSB && !FQ) qlist[qbase + k0 + kcount + (uint32_t)slot] = pid_g;  // the compaction, for the backward
+            }
+            wave_lds_sync();
+            if (base + 64 + lane < e1) {
+                pid_g = pid_n;
+                p0 = rec[(size_t)pid_g * 3];
+                p1 = rec[(size_t)pid_g * 3 + 1];
+                if (PASSB) p2 = rec[(size_t)pid_g * 3 + 2];
+                if (base + 128 + lane < e1) pid_n = list[base + 128 + lane];
+            }
+            const char* sp = reinterpret_cast<const char*>(srec) + vzero;  // (render_quadrant_1: a VGPR address)
+            const uint32_t sp0 = (uint32_t)(uintptr_t)sp;
+            auto ld_a = [&](int o) { return *reinterpret_cast<const float4*>(sp + o); };
+            auto ld_b = [&](int o) { return *reinterpret_cast<const float2*>(sp + o + 16); };
+            auto ld_c = [&](int o) {
+                const float4 cc = *reinterpret_cast<const float4*>(sp + o + 32);
+                asm volatile("" ::"v"(cc.w));  // one ds_read_b128 (render_quadrant_1)
+                return cc;
+            };
+            uint32_t mark_e = 0xFFFFFFFFu, mark_o = 0xFFFFFFFFu;
+            auto step = [&](const float4 a, const float2 bb, const float4 cc, uint32_t& mark) {
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power2 = __builtin_fmaf(a.z * dx, dx, __builtin_fmaf(a.w, dx, bb.x * dy) * dy);
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float al = fminf(0.99f, bb.y * G);
+                const bool valid = power2 <= 0.0f && al >= (1.0f / 255.0f);
+                const float a2 = valid ? al : 0.f;
+                p = p * (1.f - a2);          // (both passes: the same multiplications)
+                if (PASSB) {
+                    const float Tn = Ts * p;             // T behind this entry
+                    const bool pass = Tn >= 0.0001f;     // (can only switch off once: Ts p never grows)
+                    const float w = pass ? a2 * Tc : 0.f;
+                    Tl = pass ? Tn : Tl;
+                    Tc = Tn;
+                    C0 += cc.x * w;
+                    C1 += cc.y * w;
+                    C2 += cc.z * w;
+                    mark = (valid && pass) ? (uint32_t)(uintptr_t)sp : mark;
+                }
+            };
+            // entries [j0, j1) of the batch (sp stands at entry j0, and at entry j1 afterwards); two per trip, the reads of
+            // the next entry issued before the current one is evaluated (render_quadrant_1)
+            auto run = [&](const int j0, const int j1) {
+                float4 a0 = ld_a(0), c0 = make_float4(0, 0, 0, 0);
+                float2 b0 = ld_b(0);
+                if (PASSB) c0 = ld_c(0);
+                int j = j0;
+                for (; j + 1 < j1; j += 2) {
+                    const float4 a1 = ld_a(48);
+                    float4 c1 = make_float4(0, 0, 0, 0);
+                    if (PASSB) c1 = ld_c(48);
+                    const float2 b1 = ld_b(48);
+                    step(a0, b0, c0, mark_e);
+                    a0 = ld_a(96); b0 = ld_b(96);
+                    if (PASSB) c0 = ld_c(96);
+                    sp += 96;
+                    step(a1, b1, c1, mark_o);
+                }
+                if (j < j1) {
+                    step(a0, b0, c0, mark_e);
+                    sp += 48;
+                }
+            };
+            // (pass B) a chunk of the BACKWARD starts at every compacted index j BWD_CH, 0 < j < chunks, exactly as the
+            // one-wave kernel cuts them: its checkpoint -- T and the colour composited so far -- is written where the walk
+            // passes the index; the colour is this chunk's share, the finishing wave adds the chunks before it
+            int jc = cnt;
+            if (PASSB && chunks > 1) {
+                const uint32_t kb = k0 + kcount;
+                const uint32_t r = (BWD_CH - (kb & (BWD_CH - 1u))) & (BWD_CH - 1u);
+                if (r < (uint32_t)cnt && kb + r > 0u && kb + r < (uint32_t)chunks * BWD_CH) jc = (int)r;
+            }
+            run(0, jc);
+            if (jc < cnt) {
+                const uint32_t kb = k0 + kcount;
+                const int j = (int)((kb + (uint32_t)jc) / BWD_CH);
+                float* cp = reinterpret_cast<float*>(&A.ckpt[(quad * (size_t)(chunks - 1) + (size_t)(j - 1)) * 64 + lane]);
+                xstore(cp, Tc); xstore(cp + 1, C0); xstore(cp + 2, C1); xstore(cp + 3, C2);
+                if (lane == 0) A.ck_start[quad * (size_t)chunks + j] = kb + (uint32_t)jc;
+                run(jc, cnt);
+            }
+            if (PASSB) {
+                const uint32_t kbase = k0 + kcount;
+                const uint32_t ke = mark_e != 0xFFFFFFFFu ? kbase + (((mark_e - sp0) * 43691u) >> 21) + 1u : 0u;
+                const uint32_t ko = mark_o != 0xFFFFFFFFu ? kbase + (((mark_o - sp0) * 43691u) >> 21) : 0u;
+                last_k = max(last_k, max(ke, ko));
+                if (last_k > kbase) last = __float_as_uint(srec[(last_k - 1u - kbase) * 3 + 2].w);
+            }
+            kcount += (uint32_t)cnt;
+            // every pixel's product below the threshold: whatever T the chunk started from, nothing behind this batch is
+            // blended in this chunk or any later one (pass B takes the same exit at the same batch: the same product)
+            if (__ballot(inside && p >= 0.0001f) == 0ull) break;
+        }
+        hits = kcount;
+    };
+
+#ifdef FWDC_PROF
+    // tools/fwdc_prof.py: the constant 100 MHz clock at the phase boundaries of the long tiles' first quadrant
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+#define FWDC_T(i) pt[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define FWDC_T(i)
+#endif
+    FWDC_T(0);
+    int e0, e1;  // this chunk's entries
+    const uint32_t* __restrict__ list;
+    bool dead;
+    if (!FQ) {
+        list = A.point_list + range.x;
+        e0 = min((int)((uint32_t)c * ch), n_tile);
+        e1 = min(e0 + (int)ch, n_tile);
+        walk(std::false_type{}, list, e0, e1);
+        FWDC_T(1);
+        // ---- publish P and the hits; then the look-back
+        xstore(&rec_me[0 * 64 + lane], p);
+        xrelease();
+        if (lane == 0) xstore(&A.cw_flag[r_me], hits + 1u);
+        float T = 1.0f;
+        for (int cb = 0; cb < c; cb += 64) {
+            const int m = min(64, c - cb);
+            uint32_t f = 1u;
+            int spins = 0;
+            for (;;) {  // (wave-uniform exit)
+                if (lane < m) f = xload(&A.cw_flag[r_first + 4 * (size_t)(cb + lane)]);
+                if (__ballot(f == 0u) == 0ull || ++spins >= FWDC_SPIN_MAX) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            f = f ? f : 1u;   // (a wave that gave up: zero hits there -- a wrong quadrant, every index still inside its slice)
+            xacquire();  // (the records behind the flags)
+            k0 += wave_sum(lane < m ? ((f & ~FWDC_DEAD) - 1u) : 0u);
+            const float* __restrict__ pr = A.cw_rec + (r_first + 4 * (size_t)cb) * (FWDC_SLOTS * 64) + lane;
+            int k = 0;
+            for (; k + 4 <= m; k += 4) {  // (four loads in flight; the products in chunk order)
+                const float P0 = xload(pr + (size_t)(k + 0) * 4 * FWDC_SLOTS * 64);
+                const float P1 = xload(pr + (size_t)(k + 1) * 4 * FWDC_SLOTS * 64);
+                const float P2 = xload(pr + (size_t)(k + 2) * 4 * FWDC_SLOTS * 64);
+                const float P3 = xload(pr + (size_t)(k + 3) * 4 * FWDC_SLOTS * 64);
+                T = (((T * P0) * P1) * P2) * P3;
+            }
+            for (; k < m; k++) T = T * xload(pr + (size_t)k * 4 * FWDC_SLOTS * 64);
+        }
+        FWDC_T(2);
+        Ts = inside ? T : 0.0f;
+        xstore(&rec_me[1 * 64 + lane], Ts);
+        dead = __ballot(Ts >= 0.0001f) == 0ull;
+        if (dead && lane == 0) __hip_atomic_fetch_or(&A.cw_flag[r_me], FWDC_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        // a second render: hits, k0 and Ts are the first render's; the chunk's part of the recorded list is walked
+        list = qlist + qbase;
+        const uint32_t fme = A.src_cw_flag[r_me];
+        dead = (fme & FWDC_DEAD) != 0u;
+        for (int cb = 0; cb < c; cb += 64) {
+            const int m = min(64, c - cb);
+            k0 += wave_sum(lane < m ? ((A.src_cw_flag[r_first + 4 * (size_t)(cb + lane)] & ~FWDC_DEAD) - 1u) : 0u);
+        }
+        const int nq = (int)A.src_qcount[quad];  // (entries behind the quadrant's last contributor blend nowhere)
+        e0 = min((int)k0, nq);
+        e1 = min((int)(k0 + ((fme & ~FWDC_DEAD) - 1u)), nq);
+        Ts = A.src_cw_rec[r_me * (FWDC_SLOTS * 64) + 1 * 64 + lane];
+    }
+    if (!dead) {
+        Tl = Ts;
+        if (FQ) {
+            // (the walk numbers the chunk's entries from k0; its list positions e0.. are compacted indices already)
+            walk(std::true_type{}, list, e0, e1);
+        } else {
+            walk(std::true_type{}, list, e0, e1);
+        }
+        xstore(&rec_me[2 * 64 + lane], C0);
+        xstore(&rec_me[3 * 64 + lane], C1);
+        xstore(&rec_me[4 * 64 + lane], C2);
+        // final_T, if this chunk decides it: T after the last blended entry where the pixel stopped HERE (alive at the
+        // chunk's start, below the threshold at its end: Ts p is the next chunk's start, the same multiplication); the
+        // whole product for a pixel that is still alive behind the tile's last chunk; -1: not this chunk's to say
+        const float Tend = Ts * p;
+        const float tf = (Ts >= 0.0001f && Tend < 0.0001f) ? Tl : ((c == nch - 1 && Tend >= 0.0001f) ? Tend : -1.0f);
+        xstore(&rec_me[5 * 64 + lane], tf);
+        xstore(&rec_me[6 * 64 + lane], __uint_as_float(last_k));
+        xstore(&rec_me[7 * 64 + lane], __uint_as_float(last));
+    }
+    FWDC_T(3);
+    // ---- the quadrant's ticket: the wave that takes the last one finishes the quadrant
+    xrelease();
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&A.cw_done[quad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    FWDC_T(4);
+#ifdef FWDC_PROF
+    if (lane < 5) rec_me[8 * 64 + lane] = __uint_as_float((uint32_t)pt[lane]);
+    if (lane == 5) rec_me[8 * 64 + 5] = __uint_as_float(0u);
+    if (lane == 6) rec_me[8 * 64 + 6] = __uint_as_float(xcc_id() | ((uint32_t)blockIdx.x << 8));
+#endif
+    if (ticket != (uint32_t)(nch - 1)) return;
+    xacquire();
+    if (lane == 0) A.cw_done[quad] = 0u;  // (a second finish of the same state starts from zero without a clear)
+    const uint32_t* __restrict__ flags = FQ ? A.src_cw_flag : A.cw_flag;
+    // The live chunks come first (T only falls).  Per block of 64 chunks: lane i looks at chunk i's flag; then the live
+    // chunks' records four at a time -- every load of a group in flight before the first is used (a record is read from
+    // beyond this XCD's L2: a round trip of a microsecond or two each, and this wave is the frame's tail)
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, Tfin = 0.f;
+    uint32_t lk = 0, lp = 0, kacc = 0;
+    for (int cb = 0; cb < nch; cb += 64) {
+        const int m = min(64, nch - cb);
+        const uint32_t f = lane < m ? xload(&flags[r_first + 4 * (size_t)(cb + lane)]) : FWDC_DEAD;
+        const unsigned long long deadm = __ballot((f & FWDC_DEAD) != 0u);
+        const int nl = deadm ? (int)__builtin_ctzll(deadm) : 64;  // live chunks of this block (lanes >= m read as dead)
+        const uint32_t hv = max(f & ~FWDC_DEAD, 1u) - 1u;
+        for (int k = 0; k < nl; k += FIN_G) {
+            float s0[FIN_G], s1[FIN_G], s2[FIN_G], tf[FIN_G];
+            uint32_t lkk[FIN_G], lpk[FIN_G];
+#pragma unroll
+            for (int g = 0; g < FIN_G; g++) {
+                const bool on = k + g < nl;  // (wave-uniform)
+                const float* __restrict__ orr = A.cw_rec + (r_first + 4 * (size_t)(cb + (on ? k + g : k))) * (FWDC_SLOTS * 64) + lane;
+                s0[g] = xload(orr + 2 * 64); s1[g] = xload(orr + 3 * 64); s2[g] = xload(orr + 4 * 64);
+                tf[g] = xload(orr + 5 * 64);
+                lkk[g] = __float_as_uint(xload(orr + 6 * 64)); lpk[g] = __float_as_uint(xload(orr + 7 * 64));
+            }
+#pragma unroll
+            for (int g = 0; g < FIN_G; g++) {
+                if (k + g >= nl) break;  // (wave-uniform)
+                const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)hv, k + g);
+                if (chunks > 1 && (cb + k + g) > 0) {
+                    // the backward's checkpoints this chunk's wave wrote (at the multiples of BWD_CH inside its hits): + the
+                    // colour composited by the chunks in front of it
+                    for (uint32_t j = max(1u, (kacc + BWD_CH - 1u) / BWD_CH); j < (uint32_t)chunks && j * BWD_CH < kacc + hk; j++) {
+                        float* cp = reinterpret_cast<float*>(&A.ckpt[(quad * (size_t)(chunks - 1) + (size_t)(j - 1)) * 64 + lane]);
+                        const float y0 = xload(cp + 1), y1 = xload(cp + 2), y2 = xload(cp + 3);
+                        cp[1] = y0 + S0; cp[2] = y1 + S1; cp[3] = y2 + S2;
+                    }
+                }
+                S0 += s0[g]; S1 += s1[g]; S2 += s2[g];
+                if (tf[g] >= 0.f) Tfin = tf[g];  // (one chunk per pixel says so)
+                if (lkk[g]) { lk = lkk[g]; lp = lpk[g]; }
+                kacc += hk;
+            }
+        }
+        if (nl < 64) break;
+    }
+    {
+        const uint32_t nm = wave_max_u32(lk);
+        if (lane == 0) A.qcount[quad] = nm;
+        // chunks of the backward that have nothing to do: their first index lies behind the quadrant's last contributor (a
+        // second render does not even walk that far: its waves have not written these words)
+        if (chunks > 1 && lane >= 1 && lane < chunks && (uint32_t)lane * BWD_CH >= nm) A.ck_start[quad * (size_t)chunks + lane] = 0xFFFFFFFFu;
+    }
+    float l1 = 0.f;
+    if (inside) {
+        const size_t HW = (size_t)H * W;
+        const size_t pid = (size_t)py * W + px;
+        if (FQ) Tfin = A.src_final_T[pid];  // (the same value: the same geometry)
+        A.final_T[pid] = Tfin;
+        A.n_contrib[pid] = FQ ? A.src_n_contrib[pid] : lp;
+        A.ncon_c[pid] = lk;
+        const float o0 = S0 + Tfin * A.bg[0], o1 = S1 + Tfin * A.bg[1], o2 = S2 + Tfin * A.bg[2];
+        A.out_color[pid] = o0;
+        A.out_color[HW + pid] = o1;
+        A.out_color[2 * HW + pid] = o2;
+        if (A.l1_target) l1 = (fabsf(o0 - A.l1_target[pid]) + fabsf(o1 - A.l1_target[HW + pid])) + fabsf(o2 - A.l1_target[2 * HW + pid]);
+    }
+    if (A.l1_target) {
+        l1 = wave_sum(l1);
+        if (lane == 0) A.l1_part[quad] = l1;
+    }
+#ifdef FWDC_PROF
+    FWDC_T(5);
+    if (lane == 5) rec_me[8 * 64 + 5] = __uint_as_float((uint32_t)pt[5]);
+#endif
+}
+
+// CW: the launch also runs the chunk-parallel forward of the marked tiles (small images).  A kernel of its own: the
+// large-image kernel keeps the registers (62, no spills) it has without that code.
+template <bool FQ, bool CW>
+__device__ __forceinline__ void render_fwd_body(const FwdArgs& A, float4* __restrict__ srec) {
     int slot, q;
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.all_ones) *A.all_ones = (A.not_ones && *A.not_ones == 0ull) ? 1u : 0u;
-    render_block_map((int)blockIdx.x, A.xmap, &slot, &q);
-    if (slot < A.ntiles && !(FQ && A.not_ones && *A.not_ones == 0ull))
-        render_quadrant_1<FQ>(A, (int)(A.order[slot] & 0x7FFFFFFFu), q, srec);  // heaviest tiles first (tile_order_kernel)
+    int b = (int)blockIdx.x;
+    const bool composite = !(FQ && A.not_ones && *A.not_ones == 0ull);
+    if (CW && b < A.cw_blocks) {  // (workgroup-uniform) a worker of the chunk-parallel forward: items of its XCD's queue
+        if (composite) {
+            // Worker b takes item r = b >> 3 of the list of the XCD it runs on -- the dispatcher deals workgroups round-robin
+            // over the XCDs, starting wherever the previous launch stopped (tools/xcc_probe.hip; a -m gpu test): workgroups
+            // 8 r .. 8 r + 7 run on eight different XCDs, so r numbers the workers of every XCD and nobody
+            // pops anything (a shared queue head popped by 2048 workers serialises at 0.1-0.3 us a pop: the avatar frame's
+            // items were handed out over 100 us).  The XCD is READ (HW_REG_XCC_ID), not assumed, and the item is CLAIMED
+            // (an exchange on the item's own word, uncontended): should the dispatcher ever deal differently, two
+            // workers cannot take one item, and the one that lost takes part in the sweep below.
+            const uint32_t x = xcc_id();
+            const uint32_t n = A.cw_hdr[4 + x];
+            const uint32_t r = (uint32_t)b >> 3;
+            const uint32_t* __restrict__ items = A.cw_items + (size_t)x * (FWDC_MAX_UNITS * 4);
+            uint32_t* __restrict__ claim = A.cw_q + (size_t)x * (FWDC_MAX_UNITS * 4);
+            const int lane = threadIdx.x;
+            bool sweep = n > (uint32_t)A.cw_blocks >> 3;  // more items than workers on an XCD: every worker goes on
+            if (r < n) {
+                uint32_t old = 0;
+                if (lane == 0) old = __hip_atomic_exchange(&claim[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                if (old == 0u) render_chunk<FQ>(A, items[r], srec);
+                else sweep = true;
+            }
+            // the sweep: the LOWEST item nobody has taken, until there is none (lowest first: a taken item's predecessors are
+            // all taken, so they are running or done)
+            for (uint32_t base = 0; sweep && base < n;) {
+                const uint32_t i = base + (uint32_t)lane;
+                const uint32_t cl = i < n ? xload(&claim[i]) : 1u;
+                const unsigned long long m = __ballot(cl == 0u);
+                if (!m) { base += 64; continue; }
+                const uint32_t pick = base + (uint32_t)__builtin_ctzll(m);
+                uint32_t old = 0;
+                if (lane == 0) old = __hip_atomic_exchange(&claim[pick], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                if (old == 0u) render_chunk<FQ>(A, items[pick], srec);
+            }
+        }
+        forward_side_fill(A);
+        return;
+    }
+    if (CW) b -= A.cw_blocks;
+    render_block_map(b, A.xmap, &slot, &q);
+    if (slot < A.ntiles && composite) {
+        const uint32_t ov = A.order[slot];  // heaviest tiles first (tile_order_kernel); bit 31: rendered in chunks above
+        if (!(CW && (ov >> 31))) render_quadrant_1<FQ>(A, (int)(ov & 0x7FFFFFFFu), q, srec);
+    }
     // The side job BEHIND the wave's own work (same-box A/B, config 3, whole step: no side job 617.3 us; here 611.5 us;
     // between the wave's first gathers and its loop 624.9 us -- the stores queue in front of every wave's second batch)
     forward_side_fill(A);
+}
+
+template <bool FQ>
+__global__ __launch_bounds__(64, 8) void render_fwd_kernel(const FwdArgs A) {  // (eight waves per SIMD: at most 64 VGPRs)
+    __shared__ float4 srec[66 * 3];
+    render_fwd_body<FQ, false>(A, srec);
+}
+// (with the chunk-parallel forward: one wave less per SIMD rather than spills -- a kernel that uses scratch memory at all
+// is dispatched into the scratch ring's wave slots)
+template <bool FQ>
+__global__ __launch_bounds__(64, FWDC_WAVES_PER_SIMD) void render_fwd_cw_kernel(const FwdArgs A) {
+    __shared__ float4 srec[66 * 3];
+    render_fwd_body<FQ, true>(A, srec);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -636,8 +1098,10 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
     const FwdArgs A{reinterpret_cast<const float4*>(rec), point_list, reinterpret_cast<const uint2*>(ranges), order, bg, W, H, gx,
                     gx * gy, xmap, out_color, final_T, n_contrib, ql.qlist, ql.ncon_c, ql.qcount, ql.ckpt, ql.ck_start,
                     ql.ckpt ? ql.chunks : 1, ql.src_qcount, ql.src_n_contrib, ql.not_ones, ql.marks, ql.mark_quads, ql.marks_flag, ql.all_ones,
-                    ql.l1_target, ql.l1_part};
-    const dim3 grid(render_grid_blocks(gx * gy, xmap));
+                    ql.l1_target, ql.l1_part,
+                    ql.chunked ? FWDC_MAX_UNITS * 4 : 0, ql.cw_hdr, ql.cw_units, ql.cw_items, ql.cw_q, ql.cw_flag, ql.cw_done, ql.cw_rec, ql.src_cw_flag,
+                    ql.src_cw_rec, ql.src_final_T};
+    const dim3 grid(render_grid_blocks(gx * gy, xmap) + A.cw_blocks);
     const bool fq = ql.src_qcount != nullptr;  // a second render of the same geometry: walk the recorded quadrant lists
     // frames of few long lists (small images; GsFwdArgs.long_lists): four waves per quadrant, all used where
     // tile_order_kernel marked the tile's list as long
@@ -645,8 +1109,13 @@ int launch_render_forward(const float* rec, const uint32_t* point_list, const ui
         if (fq) hipLaunchKernelGGL(render_fwd_small_kernel<true>, grid, dim3(FWD4_BATCH), 0, s, A);
         else hipLaunchKernelGGL(render_fwd_small_kernel<false>, grid, dim3(FWD4_BATCH), 0, s, A);
     } else {
-        if (fq) hipLaunchKernelGGL(render_fwd_kernel<true>, grid, dim3(64), 0, s, A);
-        else hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(64), 0, s, A);
+        if (A.cw_blocks) {
+            if (fq) hipLaunchKernelGGL(render_fwd_cw_kernel<true>, grid, dim3(64), 0, s, A);
+            else hipLaunchKernelGGL(render_fwd_cw_kernel<false>, grid, dim3(64), 0, s, A);
+        } else {
+            if (fq) hipLaunchKernelGGL(render_fwd_kernel<true>, grid, dim3(64), 0, s, A);
+            else hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(64), 0, s, A);
+        }
     }
     GS_LAUNCH_CHECK("render_forward", 0, s);
     if (ql.l1_target)  // the fused L1 loss: the quadrants' partial sums, added in index order, over the 3 H W elements

@@ -128,7 +128,8 @@ def release_shared_geometry():
     _geom_cache.clear()
 
 
-_sizes = {}  # memo of the library's size queries (pure functions of their arguments)
+_sizes = {}  # memo of the library's size queries (pure functions of their arguments and of the tuning switches)
+_lib.tuning_listeners.append(_sizes.clear)
 
 
 def _size(fn_name, *args):

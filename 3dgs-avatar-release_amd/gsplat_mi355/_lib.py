@@ -40,7 +40,7 @@ EXPORTS = ["gs_geom_bytes", "gs_image_bytes", "gs_binning_bytes", "gs_backward_s
            "gs_last_hip_error", "gs_last_stage", "gs_build_info", "gs_profile_enable", "gs_profile_filter", "gs_profile_collect",
            "gs_l1_loss_workspace_bytes", "gs_l1_loss", "gs_bce_loss", "gs_ssim_workspace_bytes", "gs_ssim_forward", "gs_ssim_backward",
            "gs_build_covariance", "gs_build_covariance_backward", "gs_sh2rgb", "gs_sh2rgb_backward", "knn_points", "gs_densify_stats", "gs_adam_step",
-           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second", "gs_clock_probe", "gs_pair_stats"]
+           "gs_opacity_image", "gs_backward_with_opacity", "gs_tuning", "gs_profile_reserve", "gs_image_bytes_for", "gs_backward_with_second", "gs_clock_probe", "gs_pair_stats", "gs_xcc_probe"]
 
 GS_E_WORKSPACE = -5  # include/gsplat_mi355.h
 GS_E_CAPTURE = -6
@@ -116,6 +116,7 @@ def load():
         L.gs_binning_field.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_image_field.argtypes = [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         L.gs_clock_probe.argtypes = [c_void_p, c_int32, c_void_p]
+        L.gs_xcc_probe.argtypes = [c_void_p, c_int32, c_void_p]
         L.gs_pair_stats.argtypes = [POINTER(GsFwdArgs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_int64, c_void_p,
                                     c_void_p]
         L.gs_tuning.argtypes = [c_char_p, c_int]
@@ -142,9 +143,15 @@ def check(rc):
         raise RuntimeError("gsplat_mi355: " + msg)
 
 
+tuning_listeners = []  # called after every change of a tuning switch ("small_tiles" and "fwd4" change the image state's size:
+#                        whoever memoises the library's size queries forgets them here)
+
+
 def tuning(name, value):
     """Process-wide tuning switch of the library (A/B measurements)."""
     check(load().gs_tuning(name.encode(), int(value)))
+    for fn in tuning_listeners:
+        fn()
 
 
 def profile_enable(on, stage=None):
@@ -166,6 +173,15 @@ def profile_collect(max_stages=32):
     n = c_int32(0)
     check(load().gs_profile_collect(max_stages, names, ms, cnt, ctypes.byref(n)))
     return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
+
+
+def xcc_probe(dev, n_blocks=4096):
+    """The XCD every workgroup of a launch of `n_blocks` workgroups runs on (gs_xcc_probe), as a CPU int tensor."""
+    import torch
+    t = torch.zeros(int(n_blocks), dtype=torch.int32, device=dev)
+    with on_device(dev):
+        check(load().gs_xcc_probe(t.data_ptr(), int(n_blocks), stream_ptr(dev)))
+    return t.cpu()
 
 
 def clock_probe(dev, iters=8192):

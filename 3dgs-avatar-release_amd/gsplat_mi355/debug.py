@@ -76,6 +76,15 @@ def forward_state(settings, means3D, opacities, shs=None, colors_precomp=None, s
             # launch order of the tiles (heaviest first); bit 31: rendered by four waves per quadrant (small images)
             order=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 5), 4 * gx * gy, np.uint32),
         )
+        # the chunk-parallel forward's work list and hand-off words (gs_tuning "fwd4" = 2 on a small image; else absent)
+        probe = ctypes.c_void_p(0)
+        if L.gs_image_field(img.data_ptr(), W, H, 6, ctypes.byref(probe)) == 0:  # GS_OK
+            hdr = _view(img, field(L.gs_image_field, img.data_ptr(), W, H, 6), 64, np.uint32)
+            nu = int(hdr[0])
+            im["chunks"] = dict(
+                hdr=hdr,
+                units=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 7), 8 * nu, np.uint32).reshape(-1, 2),
+                flags=_view(img, field(L.gs_image_field, img.data_ptr(), W, H, 8), 16 * nu, np.uint32))
     # the tile of every list entry: the lists are stored tile after tile, so the ranges say it (upstream keeps the tile
     # id in the high half of its sort keys)
     r = im["ranges"].astype(np.int64)

@@ -324,7 +324,10 @@ int gs_adam_step(int32_t n_tensors, const GsAdamTensor* tensors, double beta1, d
  *  image:   0 ranges u32[tiles,2]   1 n_contrib u32[H,W]   2 final_T f32[H,W]
  *           3 per-quadrant compacted count up to the last contributor u32[tiles,4]
  *           4 per-pixel last contributor in compacted coordinates u32[H,W]
- *           5 launch order of the tiles u32[tiles], heaviest first; bit 31 = rendered by four waves per quadrant */
+ *           5 launch order of the tiles u32[tiles], heaviest first; bit 31 = rendered by four waves per quadrant, or in chunks
+ *           (gs_tuning "fwd4" = 2 only) 6 chunk work header u32[16] (units, entries per chunk, .., [4..11] items per XCD)
+ *           7 units u32[.,2] {tile, chunk | chunks of the tile << 16}   8 per (unit, quadrant) hits + 1 | dead << 31
+ *           9 per (unit, quadrant) record f32[8,64] */
 int gs_geom_field(void* geom, int32_t P, int32_t field, void** out);
 int gs_binning_field(void* binning, int64_t num_rendered, int32_t W, int32_t H, int32_t field, void** out);
 int gs_image_field(void* img, int32_t W, int32_t H, int32_t field, void** out);
@@ -355,13 +358,23 @@ int gs_pair_stats(const GsFwdArgs* a, const void* geom, size_t geom_bytes, const
  * device uint64 (two results, two scratch words).  Not capture-safe. */
 int gs_clock_probe(uint64_t* ticks, int32_t iters, void* stream);
 
+/* Which XCD (accelerator die with its own L2) every workgroup of a launch of `n_blocks` workgroups of 64 threads runs on:
+ * xcc[b] = HW_REG_XCC_ID of workgroup b.  The chunk-parallel forward (gs_tuning "fwd4" = 2) numbers its workers on the
+ * premise that the dispatcher deals workgroups round-robin over the XCDs, xcc[b] == b % 8 on an MI355X in SPX mode; it
+ * reads the register and claims its items, so a different deal costs speed, not the image -- this call is how the -m gpu
+ * suite checks the premise.  `xcc`: n_blocks device uint32. */
+int gs_xcc_probe(uint32_t* xcc, int32_t n_blocks, void* stream);
+
 /* process-wide tuning switches for experiments and A/B measurements.  Without effect on the results: "xcd_map" (1: the
  * four quadrant waves of a tile on one XCD), "depth_sort" (1: bucket sort, 0: LSD radix), "nt_stores" (1: the backward's
  * row-mark fill is written with streaming stores), "fwd_marks" (1: the forward's render launch sets the backward's row
  * marks on the side, 0: every backward sets them itself), "bwd_order" (1: the backward orders the tiles by the forward's
  * per-quadrant last contributors, 0: walks them in the forward's launch order).  With an effect of fp32 rounding (which kernels render a frame of few,
- * long tile lists; flip them between frames only, "small_tiles" also changes the image state's size): "fwd4" (1: four
- * waves per quadrant, four entries per step on the marked tiles), "bwd_chunks" (1: backward in chunks from the forward's
+ * long tile lists; flip them between frames only, "small_tiles" also changes the image state's size): "fwd4" (0: one wave per quadrant everywhere; 1 (default): four
+ * waves per quadrant, four entries per step on the marked tiles; 2: the marked tiles' lists cut into chunks, a wave per
+ * (chunk, quadrant) -- also changes the image state's size; the same list, contributors and stop rule, transmittance and
+ * colour sums associated per chunk), "fwdc_ch" (entries per chunk, a power of two >= 64; 256), "fwdc_div" (a tile is marked
+ * when its list is longer than the frame's pairs / this; 320), "bwd_chunks" (1: backward in chunks from the forward's
  * checkpoints), "small_tiles" (images of up to this many tiles use both whatever GsFwdArgs.long_lists says; 2048).  "shared_qlist"
  * (1: gs_forward_shared renders from the recorded quadrant lists, 0: from the tiles' lists; same bits).  "ones_fast" (1: a
  * second render whose colours are all ones is written as 1 - T of the first; 0: composited; equal to fp32 rounding) */
