@@ -227,6 +227,106 @@ __device__ __forceinline__ uint32_t tile_work(const uint2* __restrict__ ranges, 
 // One workgroup of 1024 threads.  HELD = true: every thread keeps the work of its (up to 32) tiles in registers, so the
 // inputs are loaded once, all loads in flight together (ntiles <= 32 * 1024); otherwise the phases re-read them.
 // LDS: hist[1024], wmax[16], wsum[16].
+// (The ordering without the chunk work list: the code every frame but a chunk-parallel one runs.  Kept apart from
+// tile_order_body below -- with the work list's code in the same function the list-writing launch took 41.8 us instead of
+// 34.5 at config 3, where not one line of it runs.)
+template <bool HELD>
+__device__ __forceinline__ void tile_order_plain(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
+                                                int ntiles, uint32_t* __restrict__ order, const PairCount pc,
+                                                const LongLists ll, uint32_t* hist, uint32_t* wmax, uint32_t* wsum) {
+    constexpr int PER = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    hist[tid] = 0;
+    uint32_t held[HELD ? PER : 1];
+    uint32_t mx = 0;
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {  // (the loads alone first: all of them in flight before the first is looked at)
+            if (i * 1024 >= ntiles) break;  // workgroup-uniform
+            const int t = i * 1024 + tid;
+            held[i] = t < ntiles ? tile_work(ranges, keys, mode, t) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            mx = max(mx, held[i]);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) mx = max(mx, tile_work(ranges, keys, mode, t));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) wmax[wid] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < 16; w++) mx = max(mx, wmax[w]);
+    const float scale = mx ? 1023.0f / (float)mx : 0.f;
+    auto bin_of = [&](uint32_t w) { return 1023u - min(1023u, (uint32_t)((float)w * scale)); };
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            if (i * 1024 + tid < ntiles) atomicAdd(&hist[bin_of(held[i])], 1u);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bin_of(tile_work(ranges, keys, mode, t))], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins
+    const uint32_t v = hist[tid];
+    const uint32_t x = wave_scan_incl(v);
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    hist[tid] = woff + x - v;
+    __syncthreads();
+    // Small images (mark_wide, forward only): a tile whose list is long against the frame's total keeps a quadrant wave
+    // busy for longer than the rest of the frame takes -- one wave walks n entries in ~60 n cycles, the whole frame is
+    // ~0.08 cycles per pair on 1024 SIMDs -- and is rendered by four waves per quadrant instead (render_fwd.hip): bit 31.
+    uint32_t wide_from = 0xFFFFFFFFu;
+    if (mode == 2) {
+        const unsigned long long D = *pc.dev;
+        wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / FWD4_TOTAL_DIV, 0x7FFFFFFFull));
+        if (ll.stats) {
+            // how many such tiles, and the longest list (GsFwdArgs.frame_stats: diagnostics)
+            uint32_t nlong = 0;
+            if (HELD) {
+#pragma unroll
+                for (int i = 0; i < PER; i++) {
+                    if (i * 1024 >= ntiles) break;
+                    nlong += (i * 1024 + tid < ntiles && held[i] > wide_from) ? 1u : 0u;
+                }
+            } else {
+                for (int t = tid; t < ntiles; t += 1024) nlong += tile_work(ranges, keys, mode, t) > wide_from ? 1u : 0u;
+            }
+            nlong = wave_sum(nlong);
+            __syncthreads();  // (wsum is free again: the scan above has read it)
+            if (lane == 0) wsum[wid] = nlong;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < 16; w++) tot += wsum[w];
+                __hip_atomic_store(&ll.stats[0], (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&ll.stats[1], (long long)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        if (!ll.mark) wide_from = 0xFFFFFFFFu;
+    }
+    if (HELD) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (i * 1024 >= ntiles) break;
+            const int t = i * 1024 + tid;
+            if (t < ntiles) order[atomicAdd(&hist[bin_of(held[i])], 1u)] = (uint32_t)t | (held[i] > wide_from ? 0x80000000u : 0u);
+        }
+    } else {
+        for (int t = tid; t < ntiles; t += 1024) {
+            const uint32_t wk = tile_work(ranges, keys, mode, t);
+            order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (wk > wide_from ? 0x80000000u : 0u);
+        }
+    }
+}
+
 template <bool HELD>
 __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, int mode,
                                                 int ntiles, uint32_t* __restrict__ order, const PairCount pc,
@@ -286,7 +386,7 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
     if (mode == 2) {
         const unsigned long long D = *pc.dev;
         wide_from = max(FWD4_MIN_LIST, (uint32_t)min(D / (unsigned long long)ll.total_div, 0x7FFFFFFFull));
-        if (ll.mark == 2 && D <= FWDC_SPARSE_PAIRS) wide_from = FWD4_MIN_LIST;
+        if (ll.mark == 2 && D <= FWDC_SPARSE_PAIRS) wide_from = min(FWD4_MIN_LIST, ll.ch_min);  // (every tile of two chunks or more)
         if (ll.stats || ll.mark == 2) {
             // how many such tiles, and the longest list (GsFwdArgs.frame_stats: diagnostics; the chunk size below)
             uint32_t nlong = 0;
@@ -326,43 +426,10 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
         if (!ll.mark) wide_from = 0xFFFFFFFFu;
         if (ll.mark == 2 && ch == 0) wide_from = 0xFFFFFFFFu;
     }
-    // (mark == 2) a marked tile of at least two chunks takes the next ceil(n / ch) units -- consecutive, chunk c at
-    // unit u0 + c: a chunk's wave only ever waits for waves of LOWER block indices (render_fwd.hip)
+    // the launch order; (mark == 2) only the tiles of at least two chunks keep their mark
     auto place = [&](const int t, const uint32_t wk) {
-        bool marked = wk > wide_from;
-        const uint32_t pos = atomicAdd(&hist[bin_of(wk)], 1u);  // the tile's place in the launch order (heaviest first)
-        if (marked && ch) {
-            const uint32_t nch = (wk + ch - 1u) / ch;
-            marked = nch >= 2u;
-            if (marked) {
-                const uint32_t u0 = atomicAdd(&wmax[0], nch);
-                // the tile's waves all run on ONE XCD (they hand values to each other through its L2).  Which one: the
-                // marked tiles are the first of the launch order, heaviest first, and are dealt out over the XCDs the
-                // frame's launches run on in a boustrophedon (0 1 .. 7 7 .. 1 0): every XCD gets one tile of every size
-                // class, so the chunks spread about evenly.  (A look at per-XCD load counters does not: the threads of
-                // this workgroup place their tiles in the same instant and all see the same minimum -- measured, every
-                // long tile of the avatar frame on one XCD; round-robin over the units: 384 to 872 items per XCD.)  Any
-                // choice gives the same image.  The tile's 4 nch items are appended to that XCD's list in chunk order: a
-                // wave only ever waits for items in front of its own in the list
-                const uint32_t nx = (uint32_t)__popc(xmask);
-                const uint32_t ph = pos % (2u * nx);
-                uint32_t pick = ph < nx ? ph : 2u * nx - 1u - ph, best = 0;
-                for (uint32_t x = 0; x < 8; x++) {
-                    if ((xmask >> x) & 1u) {
-                        if (pick == 0u) { best = x; break; }
-                        pick--;
-                    }
-                }
-                atomicAdd(&wsum[best], nch);
-                const uint32_t i0 = atomicAdd(&wsum[8 + best], 4u * nch);
-                uint32_t* __restrict__ items = ll.cw_items + (size_t)best * (FWDC_MAX_UNITS * 4) + i0;
-                for (uint32_t c = 0; c < nch; c++) {
-                    ll.cw_units[u0 + c] = make_uint2((uint32_t)t, c | (nch << 16));
-                    for (uint32_t q = 0; q < 4; q++) items[4 * c + q] = (u0 + c) * 4u + q;
-                }
-            }
-        }
-        order[pos] = (uint32_t)t | (marked ? 0x80000000u : 0u);
+        const bool marked = wk > wide_from && (ch == 0u || wk > ch);
+        order[atomicAdd(&hist[bin_of(wk)], 1u)] = (uint32_t)t | (marked ? 0x80000000u : 0u);
     };
     if (HELD) {
 #pragma unroll
@@ -373,6 +440,42 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
         }
     } else {
         for (int t = tid; t < ntiles; t += 1024) place(t, tile_work(ranges, keys, mode, t));
+    }
+    if (ch) {
+        // (mark == 2) The chunk work list, in a loop of its own over the launch order just written (inside the unrolled
+        // loop above its code was there 32 times: the list-writing launch 34.5 -> 41.8 us at config 3, where it never runs).
+        // A marked tile takes the next ceil(n / ch) units -- consecutive, chunk c at unit u0 + c.
+        __syncthreads();
+        for (int pos = tid; pos < ntiles; pos += 1024) {
+            const uint32_t ov = order[pos];
+            if (!(ov >> 31)) continue;
+            const int t = (int)(ov & 0x7FFFFFFFu);
+            const uint32_t nch = (tile_work(ranges, keys, mode, t) + ch - 1u) / ch;
+            const uint32_t u0 = atomicAdd(&wmax[0], nch);
+            // the tile's waves all run on ONE XCD (they hand values to each other through its L2).  Which one: the
+            // marked tiles are the first of the launch order, heaviest first, and are dealt out over the XCDs the
+            // frame's launches run on in a boustrophedon (0 1 .. 7 7 .. 1 0): every XCD gets one tile of every size
+            // class, so the chunks spread about evenly.  (A look at per-XCD load counters does not: the threads of
+            // this workgroup place their tiles in the same instant and all see the same minimum -- measured, every
+            // long tile of the avatar frame on one XCD; round-robin over the units: 384 to 872 items per XCD.)  Any
+            // choice gives the same image.  The tile's 4 nch items are appended to that XCD's list in chunk order: a
+            // wave only ever waits for items in front of its own in the list
+            const uint32_t nx = (uint32_t)__popc(xmask);
+            const uint32_t ph = (uint32_t)pos % (2u * nx);
+            uint32_t pick = ph < nx ? ph : 2u * nx - 1u - ph, best = 0;
+            for (uint32_t x = 0; x < 8; x++) {
+                if ((xmask >> x) & 1u) {
+                    if (pick == 0u) { best = x; break; }
+                    pick--;
+                }
+            }
+            const uint32_t i0 = atomicAdd(&wsum[8 + best], 4u * nch);
+            uint32_t* __restrict__ items = ll.cw_items + (size_t)best * (FWDC_MAX_UNITS * 4) + i0;
+            for (uint32_t c = 0; c < nch; c++) {
+                ll.cw_units[u0 + c] = make_uint2((uint32_t)t, c | (nch << 16));
+                for (uint32_t q = 0; q < 4; q++) items[4 * c + q] = (u0 + c) * 4u + q;
+            }
+        }
     }
     if (ll.cw_hdr) {  // (workgroup-uniform) the work list's header: units in use, entries per chunk
         __syncthreads();
@@ -413,6 +516,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 #ifndef TW_STOP_AFTER
 #define TW_STOP_AFTER 99  // tools/tw_parts.hip builds the kernel with parts left out: 1 prologue, 2 + bitmap clear, 3 + filter
 #endif
+// CW: workgroup 0 also builds the chunk-parallel forward's work list (a kernel of its own: the other one stays what it was)
+template <bool CW>
 __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __restrict__ ranklist,
                                                                  const uint32_t* __restrict__ seg_start, int P, int gx,
                                                                  int gy, int nbx, int nblocks, int nseg, int ntiles,
@@ -431,8 +536,14 @@ __global__ __launch_bounds__(TBK_THREADS) void tile_write_kernel(const uint4* __
     if (blockIdx.x == 0) {
         // Workgroup 0: the launch order of the render kernel's tile waves (heaviest first) from the tiles' pair counts --
         // nothing in this launch needs it, so it rides along instead of being a launch of one workgroup
-        if (ntiles <= 32 * 1024) tile_order_body<true>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
-        else tile_order_body<false>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        if (CW) {
+            if (ntiles <= 32 * 1024) tile_order_body<true>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+            else tile_order_body<false>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        } else if (ntiles <= 32 * 1024) {
+            tile_order_plain<true>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        } else {
+            tile_order_plain<false>(nullptr, tile_tot, 2, ntiles, order, pc, ll, bitmap, dst, dst + 16);
+        }
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -678,9 +789,14 @@ int launch_tile_lists(const uint4* ranklist, const uint32_t* chunk_pairs, uint32
     }
     {
         StageScope sc_("tile_write", s);
-        hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, s, ranklist,
-                           seg_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
-                           reinterpret_cast<uint2*>(ranges), order, pc.cap > 0 ? point_list : nullptr, pc, ll);
+        if (ll.mark == 2)
+            hipLaunchKernelGGL(tile_write_kernel<true>, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, s, ranklist,
+                               seg_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
+                               reinterpret_cast<uint2*>(ranges), order, pc.cap > 0 ? point_list : nullptr, pc, ll);
+        else
+            hipLaunchKernelGGL(tile_write_kernel<false>, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, s, ranklist,
+                               seg_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, seg_cnt, tc.tile_tot,
+                               reinterpret_cast<uint2*>(ranges), order, pc.cap > 0 ? point_list : nullptr, pc, ll);
         GS_LAUNCH_CHECK("tile_write", debug, s);
     }
     return GS_OK;

@@ -60,7 +60,7 @@ int main() {
     const int nbands = (gy + band_rows - 1) / band_rows;
     auto zero = [&] { (void)hipMemsetAsync(d_tot, 0, (size_t)ntiles * 4, 0); };
     auto count = [&] { hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)(nbands * nseg)), dim3(TC_THREADS), 0, 0, d_rank, d_chunk, d_start, P, gx, gy, band_rows, nbands, nseg, ntiles, d_seg, d_tot); };
-    auto write = [&] { hipLaunchKernelGGL(tile_write_kernel, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, 0, d_rank, d_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, d_seg, d_tot, reinterpret_cast<uint2*>(d_ranges), d_order, d_list, pc, ll); };
+    auto write = [&] { hipLaunchKernelGGL(tile_write_kernel<false>, dim3((unsigned)(1 + G.nblocks * nseg)), dim3(TBK_THREADS), 0, 0, d_rank, d_start, P, gx, gy, G.nbx, G.nblocks, nseg, ntiles, d_seg, d_tot, reinterpret_cast<uint2*>(d_ranges), d_order, d_list, pc, ll); };
     zero(); count(); (void)hipDeviceSynchronize();
     if (TW_STOP_AFTER == 99) {
         printf("D = %llu pairs, %d segments x %d blocks\n", D, nseg, G.nblocks);
