@@ -442,10 +442,19 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
         for (int t = tid; t < ntiles; t += 1024) place(t, tile_work(ranges, keys, mode, t));
     }
     if (ch) {
-        // (mark == 2) The chunk work list, in a loop of its own over the launch order just written (inside the unrolled
-        // loop above its code was there 32 times: the list-writing launch 34.5 -> 41.8 us at config 3, where it never runs).
-        // A marked tile takes the next ceil(n / ch) units -- consecutive, chunk c at unit u0 + c.
+        // (mark == 2) The chunk work list, in a pass of its own over the launch order just written (inside the unrolled
+        // loop above its code was there 32 times).  A marked tile takes the next ceil(n / ch) units -- consecutive, chunk
+        // c at unit u0 + c -- and 4 nch items of one XCD's list.  Two steps: every thread looks at one place of the order
+        // and, for a marked tile, takes the units and the items (two atomics) and notes {tile, first unit, first item |
+        // XCD << 28, chunks} in LDS; then every WAVE writes the units and items of one noted tile at a time, a lane each
+        // (one thread per tile wrote up to 116 items one after the other: + 14 us on this launch at the avatar frame).
+        // `hist` is the list-writing kernel's bitmap here (8448 words; the ordering is done with its first 1024).
         __syncthreads();
+        uint32_t* __restrict__ stash = hist;       // [FWDC_MAX_TILES][4]
+        uint32_t* __restrict__ nstash = &wmax[1];
+        if (tid == 0) *nstash = 0u;
+        __syncthreads();
+        const uint32_t nx = (uint32_t)__popc(xmask);
         for (int pos = tid; pos < ntiles; pos += 1024) {
             const uint32_t ov = order[pos];
             if (!(ov >> 31)) continue;
@@ -460,7 +469,6 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
             // long tile of the avatar frame on one XCD; round-robin over the units: 384 to 872 items per XCD.)  Any
             // choice gives the same image.  The tile's 4 nch items are appended to that XCD's list in chunk order: a
             // wave only ever waits for items in front of its own in the list
-            const uint32_t nx = (uint32_t)__popc(xmask);
             const uint32_t ph = (uint32_t)pos % (2u * nx);
             uint32_t pick = ph < nx ? ph : 2u * nx - 1u - ph, best = 0;
             for (uint32_t x = 0; x < 8; x++) {
@@ -470,11 +478,19 @@ __device__ __forceinline__ void tile_order_body(const uint2* __restrict__ ranges
                 }
             }
             const uint32_t i0 = atomicAdd(&wsum[8 + best], 4u * nch);
-            uint32_t* __restrict__ items = ll.cw_items + (size_t)best * (FWDC_MAX_UNITS * 4) + i0;
-            for (uint32_t c = 0; c < nch; c++) {
-                ll.cw_units[u0 + c] = make_uint2((uint32_t)t, c | (nch << 16));
-                for (uint32_t q = 0; q < 4; q++) items[4 * c + q] = (u0 + c) * 4u + q;
-            }
+            const uint32_t k = atomicAdd(nstash, 1u);
+            stash[4 * k] = (uint32_t)t;
+            stash[4 * k + 1] = u0;
+            stash[4 * k + 2] = i0 | (best << 28);
+            stash[4 * k + 3] = nch;
+        }
+        __syncthreads();
+        const uint32_t nk = *nstash;
+        for (uint32_t k = (uint32_t)wid; k < nk; k += 16) {
+            const uint32_t t = stash[4 * k], u0 = stash[4 * k + 1], ib = stash[4 * k + 2], nch = stash[4 * k + 3];
+            uint32_t* __restrict__ items = ll.cw_items + (size_t)(ib >> 28) * (FWDC_MAX_UNITS * 4) + (ib & 0x0FFFFFFFu);
+            for (uint32_t c = (uint32_t)lane; c < nch; c += 64) ll.cw_units[u0 + c] = make_uint2(t, c | (nch << 16));
+            for (uint32_t i = (uint32_t)lane; i < 4u * nch; i += 64) items[i] = (u0 + (i >> 2)) * 4u + (i & 3u);
         }
     }
     if (ll.cw_hdr) {  // (workgroup-uniform) the work list's header: units in use, entries per chunk

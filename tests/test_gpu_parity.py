@@ -17,6 +17,7 @@ near-threshold decisions taken the device's way), with no exempt fraction for th
 tests keep the older form: a bulk bound (<= 1e-5 of the tensor maximum for all but a small fraction of the elements)
 plus a cap on the outliers (<= 1e-2 absolute for the image)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1931,7 +1932,7 @@ def test_snug_tile_rectangles_give_bitwise_the_same_outputs_as_upstream_squares(
     try:
         _snug_vs_squares(oracle, dgr, debug, bitwise=not four_wave_forward)
     finally:
-        _lib.tuning("fwd4", 1)
+        _lib.tuning("fwd4", int(os.environ.get("GSPLAT_FWD4", "1")))  # (the process's own setting)
 
 
 def _snug_vs_squares(oracle, dgr, debug, bitwise):
